@@ -1,0 +1,156 @@
+/* rt_native.h — C-ABI of librtnative.so, the MI355X (gfx950) implementation of the reference's compute-shader path.
+ *
+ * The reference has no plugin interface of its own: its host (C#) drives the kernels through Unity's
+ * ComputeShader / ComputeBuffer / RenderTexture objects.  Each entry point below replaces exactly one of those
+ * Unity calls as the reference makes it, with the same names for kernels, constants, buffers, textures and
+ * keywords, so a host can P/Invoke this library instead of Unity's compute back end (binding: INTEGRATION.md).
+ * Citations are paths under BVH_ReSTIR_DL/Assets/Scripts/ unless they start with BVH_RIS_DL.
+ *
+ * Conventions
+ *  - Every function returns 0 on success and a negative rt_status on failure; rt_last_error() gives the message
+ *    (owned by the library, valid until the next call on that context).  No function throws or aborts.
+ *  - Handles are opaque, owned by the library, and valid until released / the context is destroyed.
+ *  - One caller thread per context.  Dispatches and uploads are enqueued in call order on one HIP stream and are
+ *    asynchronous; rt_sync() and the *_get_data() calls wait for them.  Constants are snapshotted at dispatch.
+ *  - There is no CPU fallback: rt_create() fails when no gfx950 device is usable.
+ */
+#ifndef RT_NATIVE_H
+#define RT_NATIVE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct rt_ctx_s* rt_ctx;
+typedef struct rt_shader_s* rt_shader;
+typedef struct rt_buffer_s* rt_buffer;
+typedef struct rt_texture_s* rt_texture;
+
+typedef enum {
+    RT_OK = 0,
+    RT_ERR_INVALID_ARG = -1,   /* null handle, bad size, unknown shader/kernel name, ... */
+    RT_ERR_NO_DEVICE = -2,     /* no usable gfx950 GPU, or a HIP runtime call failed */
+    RT_ERR_OUT_OF_MEMORY = -3,
+    RT_ERR_UNBOUND = -4,       /* a dispatch needs a buffer/texture/constant that was never set */
+    RT_ERR_BAD_SCENE = -5,     /* scene buffers failed validation (index out of range, BVH too deep, cycle) */
+    RT_ERR_LIMIT = -6          /* a size exceeds a documented limit of an entry point */
+} rt_status;
+
+typedef enum {
+    RT_FORMAT_R32F = 1,      /* RenderTextureFormat.RFloat (Main.cs:359) */
+    RT_FORMAT_RGBA32F = 2,   /* the 3- and 4-channel render targets and input textures, kept in fp32 */
+    RT_FORMAT_RGBA8_UNORM = 3 /* Texture2D RGBA32 inputs (ObjectHelper.cs:381); converted to fp32 on upload */
+} rt_format;
+
+/* ---- context ------------------------------------------------------------------------------------------- */
+
+/* Stands in for the Unity graphics device.  device_id is the HIP device ordinal this process renders on
+ * (one process per GPU).  Fails with RT_ERR_NO_DEVICE when that device is not a gfx950 part. */
+int rt_create(int device_id, rt_ctx* out);
+void rt_destroy(rt_ctx ctx);
+/* Waits for all work enqueued on the context (Unity has no explicit equivalent; readbacks imply it). */
+int rt_sync(rt_ctx ctx);
+const char* rt_last_error(rt_ctx ctx);
+/* The HIP stream (hipStream_t) the context enqueues on, for callers that time or order work against it. */
+void* rt_stream(rt_ctx ctx);
+
+/* Multi-GPU image sharding (no counterpart in the reference, which is single-GPU): restricts every per-pixel
+ * kernel of this context to image rows [row0, row1).  Pixel coordinates, RNG seeds and buffer indexing stay
+ * global, so a band computes bit for bit what the full frame computes there.  row1 <= 0 restores full frames. */
+int rt_set_row_band(rt_ctx ctx, int row0, int row1);
+
+/* ---- shaders: the ComputeShader assets referenced by Main.cs:46-48 --------------------------------------- */
+
+/* name is one of "ReSTIR_BVH_RayTracer", "RIS_BVH_RayTracer", "PreCalc", "PostProcessor". */
+int rt_shader_open(rt_ctx ctx, const char* name, rt_shader* out);
+void rt_shader_close(rt_shader sh);
+
+/* ComputeShader.FindKernel (ComputeHelper.cs:16,23).  Returns the kernel index (>= 0) or a negative rt_status.
+ * ReSTIR: InitialTrace 0, SpatialReusePass 1, TransferToOriginal 2, TemporalReuse 3, TraceRays 4
+ * (ComputeShaders/ReSTIR_BVH_RayTracer.compute:1-5); RIS: GenerateCandidates 0, TraceRays 1
+ * (BVH_RIS_DL/.../RIS_BVH_RayTracer.compute:1-2); PreCalc: CalcTriNormals 0; PostProcessor: AccumulateFrames 0. */
+int rt_find_kernel(rt_shader sh, const char* name);
+
+/* ComputeShader.Dispatch (ComputeHelper.cs:16,23).  Thread-group sizes are fixed per kernel as in
+ * ComputeShaders/Constants.hlsl:7-9 (8x8x1 for the tracer and post-process kernels, 256x1x1 for PreCalc). */
+int rt_dispatch(rt_shader sh, int kernel, int groups_x, int groups_y, int groups_z);
+
+/* ComputeShader.EnableKeyword / DisableKeyword (Main.cs:252-257): "VIS_REUSE", "WEIGHT_RECALC", "BRDF".
+ * Unknown keywords are ignored, as Unity does. */
+int rt_enable_keyword(rt_shader sh, const char* keyword);
+int rt_disable_keyword(rt_shader sh, const char* keyword);
+
+/* ComputeShader.SetInt / SetFloat / SetBool / SetInts / SetVector / SetMatrix
+ * (Main.cs:138-140,190-199,217-267,395-396; ShaderHelper.cs:18-19,31,38; ObjectHelper.cs:508-511,637,647,686,696).
+ * Constants live in a typeless table of 32-bit words keyed by name, exactly like a constant buffer: SetInts on
+ * a float2 constant stores integer bit patterns (the reference does this for TextureAtlasDims and
+ * EnvironmentMapTexDims).  Names the shader does not declare are accepted and ignored, as Unity does.
+ * rt_set_vector takes 4 floats; rt_set_matrix takes 16 floats in column-major order (Unity's Matrix4x4);
+ * a float3x3 constant uses the upper-left 3x3. */
+int rt_set_int(rt_shader sh, const char* name, int value);
+int rt_set_float(rt_shader sh, const char* name, float value);
+int rt_set_bool(rt_shader sh, const char* name, int value);
+int rt_set_ints(rt_shader sh, const char* name, const int* values, int count);
+int rt_set_vector(rt_shader sh, const char* name, const float values[4]);
+int rt_set_matrix(rt_shader sh, const char* name, const float values[16]);
+
+/* ComputeShader.SetBuffer(kernelIndex, name, buffer) (ShaderHelper.cs:9-72). */
+int rt_set_buffer(rt_shader sh, int kernel, const char* name, rt_buffer buf);
+/* One buffer name has no counterpart in the reference: "TraceRecords" (stride 32, one record per pixel), bound to
+ * ReSTIR kernel 0 and/or 4.  While it is bound those dispatches run instrumented variants that also write, per
+ * pixel, 8 dwords: closest-hit triangle, scene object, BVH visit-order hash of the primary ray, selected light
+ * object, selected light triangle, visit hash and closest-hit triangle of the shadow ray, visit hash of the rays
+ * cast by TraceRays.  Parity tests compare them with the oracle's records. */
+/* ComputeShader.SetTexture(kernelIndex, name, texture) (Main.cs:262-268,319-378). */
+int rt_set_texture(rt_shader sh, int kernel, const char* name, rt_texture tex);
+
+/* ---- buffers: ComputeBuffer ------------------------------------------------------------------------------ */
+
+/* new ComputeBuffer(count, stride) (ComputeHelper.cs:75,98).  Contents start zeroed. */
+int rt_buffer_create(rt_ctx ctx, int64_t count, int stride, rt_buffer* out);
+/* ComputeBuffer.SetData (ComputeHelper.cs:76).  The library copies; the caller keeps `src`. */
+int rt_buffer_set_data(rt_buffer buf, const void* src, size_t bytes);
+/* ComputeBuffer.GetData.  Waits for enqueued work, then copies `bytes` from the start of the buffer, always in
+ * the reference's array-of-structures layout, whatever layout the library keeps internally. */
+int rt_buffer_get_data(rt_buffer buf, void* dst, size_t bytes);
+/* ComputeBuffer.Release (ComputeHelper.cs:203-214); NULL is ignored. */
+void rt_buffer_release(rt_buffer buf);
+int64_t rt_buffer_count(rt_buffer buf);
+int rt_buffer_stride(rt_buffer buf);
+
+/* ---- textures: RenderTexture / Texture2D ----------------------------------------------------------------- */
+
+/* TextureHelper.CreateTexture (TextureHelper.cs:118-156) and `new RenderTexture(..., RFloat)` (Main.cs:359).
+ * Contents start zeroed.  Reads outside the texture return 0 and writes outside are dropped. */
+int rt_texture_create(rt_ctx ctx, int width, int height, rt_format format, rt_texture* out);
+/* Texture2D pixel upload; `src` is width*height texels of the texture's format, row-major, row 0 first. */
+int rt_texture_set_data(rt_texture tex, const void* src, size_t bytes);
+/* Readback (RenderTexture -> Texture2D.ReadPixels, Main.cs:544-557): fp32 texels (1 or 4 floats per texel). */
+int rt_texture_get_data(rt_texture tex, void* dst, size_t bytes);
+void rt_texture_release(rt_texture tex);
+
+/* ---- measurement (no counterpart in the reference) -------------------------------------------------------- */
+
+/* Work counters of a (shader, kernel) pair, summed over every dispatch since they were last read.
+ * rt_enable_stats level: 0 off (default), 1 counts rays and active pixels (negligible cost), 2 counts everything
+ * (runs instrumented kernel variants).  rt_get_stats waits for enqueued work, returns the sums and resets them. */
+typedef struct {
+    uint64_t rays;       /* GetRayCollision calls */
+    uint64_t pops;       /* BVH nodes popped */
+    uint64_t bvChecks;   /* child boxes tested */
+    uint64_t objVisits;  /* scene-object leaf iterations */
+    uint64_t triIters;   /* leaf triangle-loop iterations */
+    uint64_t triChecks;  /* ray/triangle tests (triangles passing the back-face pre-cull) */
+    uint64_t validNeighbours; /* SpatialReusePass neighbour reservoirs fetched */
+    uint64_t activePixels;
+} rt_dispatch_stats;
+int rt_enable_stats(rt_ctx ctx, int level);
+int rt_get_stats(rt_shader sh, int kernel, rt_dispatch_stats* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RT_NATIVE_H */

@@ -1,0 +1,397 @@
+"""Thin ctypes layer over include/rt_native.h and host/rth_api.h (no computation happens in Python)."""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+
+# numpy views of the buffer ABI (include/rt_types.h)
+DTYPES = {
+    "BV": np.dtype([("min", "<f4", 3), ("max", "<f4", 3), ("indexA", "<i4"), ("indexB", "<i4")]),
+    "Triangle": np.dtype([("v", "<i4", 3), ("localNormal", "<f4", 3), ("area", "<f4")]),
+    "Vertex": np.dtype([("pos", "<f4", 3), ("uv", "<f4", 2)]),
+    "SceneObject": np.dtype([("worldToLocal", "<f4", 16), ("localToWorld", "<f4", 16), ("materialIndex", "<i4"),
+                             ("bvStartIndex", "<i4"), ("maxDepthBVH", "<i4"), ("areaApprox", "<f4"),
+                             ("min", "<f4", 3), ("max", "<f4", 3)]),
+    "LightObject": np.dtype([("localToWorld", "<f4", 16), ("areaApprox", "<f4"), ("brightness", "<f4"),
+                             ("triStart", "<i4"), ("totTris", "<i4")]),
+    "Material": np.dtype([("brightness", "<f4"), ("col", "<f4", 3), ("colTexLoc", "<i4", 2), ("colTexDims", "<i4", 2),
+                          ("bump", "<f4"), ("bumpTexLoc", "<i4", 2), ("bumpTexDims", "<i4", 2),
+                          ("roughness", "<f4"), ("roughnessTexLoc", "<i4", 2), ("roughnessTexDims", "<i4", 2),
+                          ("metallicity", "<f4"), ("metallicityTexLoc", "<i4", 2), ("metallicityTexDims", "<i4", 2),
+                          ("normalsTexLoc", "<i4", 2), ("normalsTexDims", "<i4", 2)]),
+    "HitInfo": np.dtype([("dst", "<f4"), ("hitPoint", "<f4", 3), ("uv", "<f4", 2), ("normal", "<f4", 3),
+                         ("incomingDir", "<f4", 3), ("materialIndex", "<i4")]),
+    "Reservoir": np.dtype([("dir", "<f4", 3), ("hitPoint", "<f4", 3), ("normal", "<f4", 3), ("brdf", "<f4"),
+                           ("chosenWeight", "<f4"), ("totWeights", "<f4"), ("totCandidates", "<f4")]),
+    "TraceRecord": np.dtype([("triIndex", "<i4"), ("objIndex", "<i4"), ("visitHash", "<u4"), ("lightObj", "<i4"),
+                             ("lightTri", "<i4"), ("shadowVisitHash", "<u4"), ("shadowTri", "<i4"),
+                             ("bounceVisitHash", "<u4")]),
+    "Int2": np.dtype([("x", "<i4"), ("y", "<i4")]),
+}
+assert [DTYPES[k].itemsize for k in ("BV", "Triangle", "Vertex", "SceneObject", "LightObject", "Material", "HitInfo",
+                                     "Reservoir", "TraceRecord")] == [32, 28, 20, 168, 80, 108, 52, 52, 32]
+
+RT_FORMAT_R32F, RT_FORMAT_RGBA32F, RT_FORMAT_RGBA8_UNORM = 1, 2, 3
+
+
+class NativeError(RuntimeError):
+    pass
+
+
+_native = None
+_host = None
+
+
+def native_lib():
+    """librtnative.so.  Raises if it has not been built: there is no fallback implementation."""
+    global _native
+    if _native is None:
+        path = os.path.join(_HERE, "librtnative.so")
+        if not os.path.exists(path):
+            raise NativeError(f"{path} is missing: build it with `make native` (no CPU fallback exists)")
+        lib = C.CDLL(path, mode=C.RTLD_GLOBAL)
+        vp, ci, cs, cf = C.c_void_p, C.c_int, C.c_char_p, C.c_float
+        sig = {
+            "rt_create": (ci, [ci, C.POINTER(vp)]), "rt_destroy": (None, [vp]), "rt_sync": (ci, [vp]),
+            "rt_last_error": (cs, [vp]), "rt_stream": (vp, [vp]), "rt_set_row_band": (ci, [vp, ci, ci]),
+            "rt_shader_open": (ci, [vp, cs, C.POINTER(vp)]), "rt_shader_close": (None, [vp]),
+            "rt_find_kernel": (ci, [vp, cs]), "rt_dispatch": (ci, [vp, ci, ci, ci, ci]),
+            "rt_enable_keyword": (ci, [vp, cs]), "rt_disable_keyword": (ci, [vp, cs]),
+            "rt_set_int": (ci, [vp, cs, ci]), "rt_set_float": (ci, [vp, cs, cf]), "rt_set_bool": (ci, [vp, cs, ci]),
+            "rt_set_ints": (ci, [vp, cs, C.POINTER(ci), ci]), "rt_set_vector": (ci, [vp, cs, C.POINTER(cf)]),
+            "rt_set_matrix": (ci, [vp, cs, C.POINTER(cf)]),
+            "rt_set_buffer": (ci, [vp, ci, cs, vp]), "rt_set_texture": (ci, [vp, ci, cs, vp]),
+            "rt_buffer_create": (ci, [vp, C.c_int64, ci, C.POINTER(vp)]),
+            "rt_buffer_set_data": (ci, [vp, vp, C.c_size_t]), "rt_buffer_get_data": (ci, [vp, vp, C.c_size_t]),
+            "rt_buffer_release": (None, [vp]), "rt_buffer_count": (C.c_int64, [vp]), "rt_buffer_stride": (ci, [vp]),
+            "rt_texture_create": (ci, [vp, ci, ci, ci, C.POINTER(vp)]),
+            "rt_texture_set_data": (ci, [vp, vp, C.c_size_t]), "rt_texture_get_data": (ci, [vp, vp, C.c_size_t]),
+            "rt_texture_release": (None, [vp]),
+            "rt_enable_stats": (ci, [vp, ci]), "rt_get_stats": (ci, [vp, ci, vp]),
+        }
+        for name, (res, args) in sig.items():
+            fn = getattr(lib, name)
+            fn.restype, fn.argtypes = res, args
+        _native = lib
+    return _native
+
+
+class MainConfig(C.Structure):
+    """rth_main_config (host/rth_api.h): the inspector fields of Main (Main.cs:8-53) that reach the compute path."""
+    _fields_ = [("Resolution", C.c_int32 * 2), ("fieldOfView", C.c_float), ("MaxBounceCount", C.c_int32),
+                ("ScatterProbability", C.c_float), ("DefocusStrength", C.c_float), ("FocalPlaneFactor", C.c_float),
+                ("DebugMaxTriChecks", C.c_int32), ("DebugMaxBVChecks", C.c_int32),
+                ("SceneObjectReservoirTestsNum", C.c_int32), ("TriReservoirTestsNum", C.c_int32),
+                ("CandidateReservoirTestsNum", C.c_int32), ("SpatialReuseIterations", C.c_int32),
+                ("TemporalCandidatesNum", C.c_int32), ("SpatialReuseBlur", C.c_int32),
+                ("TemporalPrecisionThreshold", C.c_float), ("TemporalReuseWeight", C.c_float),
+                ("PixelMovementThreshold", C.c_float), ("SpatialHitPointDiffThreshold", C.c_float),
+                ("SpatialNormalsAngleThreshold", C.c_float), ("SpatialBRDFThreshold", C.c_float),
+                ("VisibilityReuseThreshold", C.c_float), ("DoVisibilityReuse", C.c_int32),
+                ("DoWeightRecalc", C.c_int32), ("DoBRDF", C.c_int32), ("cameraPosition", C.c_float * 3),
+                ("cameraRotation", C.c_float * 4), ("frameRandBase", C.c_uint32), ("frameRandStep", C.c_uint32)]
+
+
+class _MaterialInput(C.Structure):
+    _fields_ = [("brightness", C.c_float), ("col", C.c_float * 3), ("roughness", C.c_float),
+                ("metallicity", C.c_float), ("bump", C.c_float)]
+
+
+class _SceneData(C.Structure):
+    _fields_ = [("BVs", C.c_void_p), ("nBVs", C.c_int64), ("Vertices", C.c_void_p), ("nVertices", C.c_int64),
+                ("Triangles", C.c_void_p), ("nTriangles", C.c_int64), ("SceneObjects", C.c_void_p),
+                ("nSceneObjects", C.c_int64), ("LightObjects", C.c_void_p), ("nLightObjects", C.c_int64),
+                ("Materials", C.c_void_p), ("nMaterials", C.c_int64), ("ComponentDatas", C.c_void_p),
+                ("nComponentDatas", C.c_int64), ("maxBVHDepth", C.c_int32), ("emittingObjectsNum", C.c_int32),
+                ("sceneBVHStartIndex", C.c_int32), ("totArea", C.c_float)]
+
+
+class DispatchStats(C.Structure):
+    _fields_ = [(n, C.c_uint64) for n in ("rays", "pops", "bvChecks", "objVisits", "triIters", "triChecks",
+                                          "validNeighbours", "activePixels")]
+
+    def as_dict(self):
+        return {n: int(getattr(self, n)) for n, _ in self._fields_}
+
+
+def host_lib():
+    """librthost.so (scene builder + frame driver).  Loading it also loads librtnative.so."""
+    global _host
+    if _host is None:
+        native_lib()
+        path = os.path.join(_HERE, "librthost.so")
+        if not os.path.exists(path):
+            raise NativeError(f"{path} is missing: build it with `make host`")
+        lib = C.CDLL(path)
+        vp, ci, cs = C.c_void_p, C.c_int, C.c_char_p
+        fp = C.POINTER(C.c_float)
+        sig = {
+            "rth_mesh_create": (vp, [vp, ci, vp, ci]), "rth_mesh_load": (vp, [cs]), "rth_mesh_subdivide9": (vp, [vp]),
+            "rth_mesh_jitter": (vp, [vp, C.c_uint32, C.c_float]), "rth_mesh_disc": (vp, [ci]),
+            "rth_mesh_free": (None, [vp]), "rth_mesh_counts": (ci, [vp, C.POINTER(ci), C.POINTER(ci)]),
+            "rth_mesh_vertices": (vp, [vp]), "rth_mesh_triangles": (vp, [vp]),
+            "rth_scene_create": (vp, [ci, ci]), "rth_scene_free": (None, [vp]),
+            "rth_scene_add_material": (ci, [vp, C.POINTER(_MaterialInput)]), "rth_scene_add_mesh": (ci, [vp, vp]),
+            "rth_scene_add_object": (ci, [vp, ci, fp, fp, fp, ci, ci]), "rth_scene_build": (ci, [vp, ci]),
+            "rth_scene_get": (ci, [vp, C.POINTER(_SceneData)]), "rth_world_to_local": (None, [fp, fp, fp, fp, fp]),
+            "rth_view_space_dims": (None, [C.c_float, ci, ci, fp]), "rth_camera_matrices": (None, [fp, fp, fp, fp]),
+            "rth_main_default_config": (None, [C.POINTER(MainConfig)]),
+            "rth_main_create": (vp, [vp, C.POINTER(MainConfig), vp, ci, ci]), "rth_main_destroy": (None, [vp]),
+            "rth_main_last_error": (cs, [vp]), "rth_main_render_frame": (ci, [vp]),
+            "rth_main_update_per_frame": (ci, [vp]), "rth_main_run_restir_shader": (ci, [vp]),
+            "rth_main_run_post_processing": (ci, [vp]), "rth_main_run_stage": (ci, [vp, ci]),
+            "rth_main_frame_count": (ci, [vp]), "rth_main_buffer": (vp, [vp, cs]), "rth_main_texture": (vp, [vp, cs]),
+            "rth_main_shader": (vp, [vp, cs]),
+        }
+        for name, (res, args) in sig.items():
+            fn = getattr(lib, name)
+            fn.restype, fn.argtypes = res, args
+        _host = lib
+    return _host
+
+
+def _f3(v):
+    return (C.c_float * 3)(*[float(x) for x in v])
+
+
+def world_to_local(position, euler_deg, scale):
+    w2l, l2w = (C.c_float * 16)(), (C.c_float * 16)()
+    host_lib().rth_world_to_local(_f3(position), _f3(euler_deg), _f3(scale), w2l, l2w)
+    return np.array(w2l, dtype=np.float32), np.array(l2w, dtype=np.float32)
+
+
+def default_config():
+    cfg = MainConfig()
+    host_lib().rth_main_default_config(C.byref(cfg))
+    return cfg
+
+
+class Mesh:
+    def __init__(self, handle):
+        if not handle:
+            raise NativeError("mesh creation failed")
+        self.h = handle
+
+    @classmethod
+    def load(cls, path):
+        return cls(host_lib().rth_mesh_load(path.encode()))
+
+    @classmethod
+    def disc(cls, ntris):
+        return cls(host_lib().rth_mesh_disc(ntris))
+
+    @classmethod
+    def from_arrays(cls, verts, tris):
+        verts = np.ascontiguousarray(verts, dtype=DTYPES["Vertex"])
+        tris = np.ascontiguousarray(tris, dtype=np.int32)
+        return cls(host_lib().rth_mesh_create(verts.ctypes.data, len(verts), tris.ctypes.data, len(tris)))
+
+    def subdivide9(self):
+        return Mesh(host_lib().rth_mesh_subdivide9(self.h))
+
+    def jitter(self, seed, amplitude):
+        return Mesh(host_lib().rth_mesh_jitter(self.h, seed, amplitude))
+
+    def counts(self):
+        nv, nt = C.c_int(), C.c_int()
+        host_lib().rth_mesh_counts(self.h, C.byref(nv), C.byref(nt))
+        return nv.value, nt.value
+
+    def arrays(self):
+        nv, nt = self.counts()
+        v = np.ctypeslib.as_array(C.cast(host_lib().rth_mesh_vertices(self.h), C.POINTER(C.c_uint8)), (nv * 20,))
+        t = np.ctypeslib.as_array(C.cast(host_lib().rth_mesh_triangles(self.h), C.POINTER(C.c_int32)), (nt, 3))
+        return v.view(DTYPES["Vertex"]).copy(), t.copy()
+
+    def __del__(self):
+        if getattr(self, "h", None) and _host is not None:
+            _host.rth_mesh_free(self.h)
+            self.h = None
+
+
+class Scene:
+    """rth_scene: the registered objects of ObjectHelper plus ConstructScene()."""
+
+    def __init__(self, split_resolution=5, max_depth_scene_bvh=10):
+        self.h = host_lib().rth_scene_create(split_resolution, max_depth_scene_bvh)
+        if not self.h:
+            raise NativeError("scene creation failed")
+        self._data = None
+
+    def add_material(self, brightness, col, roughness=0.0, metallicity=0.0, bump=0.0):
+        m = _MaterialInput(brightness, (C.c_float * 3)(*col), roughness, metallicity, bump)
+        return host_lib().rth_scene_add_material(self.h, C.byref(m))
+
+    def add_mesh(self, mesh):
+        return host_lib().rth_scene_add_mesh(self.h, mesh.h)
+
+    def add_object(self, mesh_id, position, euler_deg, scale, material_index, max_depth_bvh):
+        r = host_lib().rth_scene_add_object(self.h, mesh_id, _f3(position), _f3(euler_deg), _f3(scale), material_index,
+                                            max_depth_bvh)
+        if r < 0:
+            raise NativeError("rth_scene_add_object failed")
+        return r
+
+    def build(self, threads=0):
+        if host_lib().rth_scene_build(self.h, threads) != 0:
+            raise NativeError("rth_scene_build failed")
+        d = _SceneData()
+        if host_lib().rth_scene_get(self.h, C.byref(d)) != 0:
+            raise NativeError("rth_scene_get failed")
+        self._data = d
+        return self
+
+    def _arr(self, ptr, n, key):
+        dt = DTYPES[key]
+        raw = np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_uint8)), (int(n) * dt.itemsize,))
+        return raw.view(dt).copy()
+
+    def arrays(self):
+        """Copies of the flat buffers ConstructScene returns (ObjectHelper.cs:737) plus the scalar constants."""
+        d = self._data
+        return {
+            "BVs": self._arr(d.BVs, d.nBVs, "BV"), "Vertices": self._arr(d.Vertices, d.nVertices, "Vertex"),
+            "Triangles": self._arr(d.Triangles, d.nTriangles, "Triangle"),
+            "SceneObjects": self._arr(d.SceneObjects, d.nSceneObjects, "SceneObject"),
+            "LightObjects": self._arr(d.LightObjects, d.nLightObjects, "LightObject"),
+            "Materials": self._arr(d.Materials, d.nMaterials, "Material"),
+            "ComponentDatas": self._arr(d.ComponentDatas, d.nComponentDatas, "Int2"),
+            "maxBVHDepth": int(d.maxBVHDepth), "emittingObjectsNum": int(d.emittingObjectsNum),
+            "sceneBVHStartIndex": int(d.sceneBVHStartIndex), "totArea": float(d.totArea),
+        }
+
+    def __del__(self):
+        if getattr(self, "h", None) and _host is not None:
+            _host.rth_scene_free(self.h)
+            self.h = None
+
+
+class RtContext:
+    """rt_ctx plus Unity-shaped helpers used by the per-kernel parity tests (all calls go through the C-ABI)."""
+
+    def __init__(self, device_id=0):
+        self.lib = native_lib()
+        h = C.c_void_p()
+        rc = self.lib.rt_create(device_id, C.byref(h))
+        if rc != 0:
+            raise NativeError(f"rt_create({device_id}) failed with status {rc}: no usable gfx950 device")
+        self.h = h
+
+    def check(self, rc, what=""):
+        if rc < 0:
+            raise NativeError(f"{what}: status {rc}: {self.lib.rt_last_error(self.h).decode()}")
+        return rc
+
+    def sync(self):
+        self.check(self.lib.rt_sync(self.h), "rt_sync")
+
+    def stream(self):
+        return self.lib.rt_stream(self.h)
+
+    def set_row_band(self, row0, row1):
+        self.check(self.lib.rt_set_row_band(self.h, row0, row1), "rt_set_row_band")
+
+    def enable_stats(self, level):
+        self.check(self.lib.rt_enable_stats(self.h, level), "rt_enable_stats")
+
+    def open_shader(self, name):
+        h = C.c_void_p()
+        self.check(self.lib.rt_shader_open(self.h, name.encode(), C.byref(h)), f"rt_shader_open({name})")
+        return h
+
+    def create_buffer(self, count, stride, data=None):
+        h = C.c_void_p()
+        self.check(self.lib.rt_buffer_create(self.h, count, stride, C.byref(h)), "rt_buffer_create")
+        if data is not None:
+            self.set_buffer_data(h, data)
+        return h
+
+    def set_buffer_data(self, buf, data):
+        data = np.ascontiguousarray(data)
+        self.check(self.lib.rt_buffer_set_data(buf, data.ctypes.data, data.nbytes), "rt_buffer_set_data")
+
+    def get_buffer(self, buf, dtype):
+        n = self.lib.rt_buffer_count(buf)
+        out = np.empty(n, dtype=dtype)
+        self.check(self.lib.rt_buffer_get_data(buf, out.ctypes.data, out.nbytes), "rt_buffer_get_data")
+        return out
+
+    def create_texture(self, w, h, fmt):
+        t = C.c_void_p()
+        self.check(self.lib.rt_texture_create(self.h, w, h, fmt, C.byref(t)), "rt_texture_create")
+        return t
+
+    def get_texture(self, tex, w, h, channels):
+        out = np.empty((h, w, channels) if channels > 1 else (h, w), dtype=np.float32)
+        self.check(self.lib.rt_texture_get_data(tex, out.ctypes.data, out.nbytes), "rt_texture_get_data")
+        return out
+
+    def get_stats(self, shader, kernel):
+        s = DispatchStats()
+        self.check(self.lib.rt_get_stats(shader, kernel, C.byref(s)), "rt_get_stats")
+        return s.as_dict()
+
+    def close(self):
+        if self.h:
+            self.lib.rt_destroy(self.h)
+            self.h = None
+
+
+class Driver:
+    """rth_main: the C++ restatement of Main.cs driving a context through the C-ABI."""
+
+    def __init__(self, ctx, cfg, scene, row0=0, row1=0):
+        self.ctx, self.cfg, self.scene = ctx, cfg, scene
+        self.lib = host_lib()
+        self.h = self.lib.rth_main_create(ctx.h, C.byref(cfg), scene.h, row0, row1)
+        if not self.h:
+            raise NativeError("rth_main_create failed: " + ctx.lib.rt_last_error(ctx.h).decode())
+        self.W, self.H = cfg.Resolution[0], cfg.Resolution[1]
+
+    def _check(self, rc, what):
+        if rc != 0:
+            raise NativeError(f"{what}: {self.lib.rth_main_last_error(self.h).decode()}")
+
+    def render_frame(self):
+        self._check(self.lib.rth_main_render_frame(self.h), "render_frame")
+
+    def update_per_frame(self):
+        self._check(self.lib.rth_main_update_per_frame(self.h), "update_per_frame")
+
+    def run_stage(self, stage):
+        self._check(self.lib.rth_main_run_stage(self.h, stage), f"run_stage({stage})")
+
+    def run_post_processing(self):
+        self._check(self.lib.rth_main_run_post_processing(self.h), "run_post_processing")
+
+    def shader(self, name="rt"):
+        return self.lib.rth_main_shader(self.h, name.encode())
+
+    def buffer_handle(self, name):
+        h = self.lib.rth_main_buffer(self.h, name.encode())
+        if not h:
+            raise NativeError(f"no driver buffer named {name}")
+        return h
+
+    def texture_handle(self, name):
+        h = self.lib.rth_main_texture(self.h, name.encode())
+        if not h:
+            raise NativeError(f"no driver texture named {name}")
+        return h
+
+    _BUF_DTYPE = {"Candidates": "Reservoir", "CandidatesB": "Reservoir", "TemporalFrameBuffer": "Reservoir",
+                  "HitInfos": "HitInfo", "Triangles": "Triangle", "BVs": "BV", "Vertices": "Vertex"}
+
+    def buffer(self, name):
+        return self.ctx.get_buffer(self.buffer_handle(name), DTYPES[self._BUF_DTYPE[name]])
+
+    def texture(self, name):
+        ch = 1 if name == "DepthBuffer" else 4
+        return self.ctx.get_texture(self.texture_handle(name), self.W, self.H, ch)
+
+    def close(self):
+        if self.h:
+            self.lib.rth_main_destroy(self.h)
+            self.h = None

@@ -1,0 +1,103 @@
+// rt_device.h — data structures shared by the host side of librtnative (rt_native.hip) and its gfx950 kernels.
+//
+// Internal to the library; nothing here crosses the C-ABI.  The ABI-level layouts are in include/rt_types.h.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/rt_types.h"
+
+namespace rtn {
+
+// ---- internal memory layouts (HBM) -------------------------------------------------------------------------
+//
+// Wide BVH node, 64 bytes, one per BV index (only the slots of internal nodes are filled or ever read).
+// It holds what one traversal step needs — both children's boxes and both children's stack entries — so an
+// internal visit is ONE aligned 64-byte fetch instead of the reference's three dependent 32-byte BV fetches
+// (BVH_ReSTIR_DL/.../ReSTIR_BVH_RayTracer.compute:171,198-199).
+//   q0 = minA.xyz, maxA.x   q1 = maxA.yz, minB.xy   q2 = minB.z, maxB.xyz   q3 = entryA, entryB, 0, 0
+//
+// Stack entry (one dword):
+//   bit31 = 1            leaf, components [start, start+count): count = bits 26..30, start = bits 0..25
+//   bit31 = 0, bit30 = 1 leaf whose range does not fit the inline form; low 30 bits = BV index to read it from
+//   bit31 = 0, bit30 = 0 internal node; low 30 bits = BV index (= index of its wide record)
+constexpr uint32_t ENTRY_LEAF = 0x80000000u;
+constexpr uint32_t ENTRY_LEAF_INDIRECT = 0x40000000u;
+constexpr uint32_t ENTRY_INDEX_MASK = 0x3fffffffu;
+constexpr int ENTRY_INLINE_MAX_COUNT = 31;
+constexpr int ENTRY_INLINE_MAX_START = (1 << 26) - 1;
+
+// Baked triangle, 64 bytes, one per Triangle: everything the leaf loop needs in one aligned fetch instead of a
+// 28-byte Triangle plus three dependent 20-byte Vertex gathers (:121-123,181).
+//   q0 = v0.xyz, N.x   q1 = edgeAB.xyz, N.y   q2 = edgeAC.xyz, N.z   q3 = localNormal.xyz, 0
+// with N = cross(edgeAB, edgeAC), computed with the same fp32 operations the intersection routine would use.
+
+// Per-pixel records are kept as planes of 16-byte elements (structure of arrays): a 52-byte reservoir or
+// hit record of `count` pixels is stored as three float4 planes followed by one float plane, in the same
+// 52*count bytes.  Every access is then one coalesced 16-byte-per-lane load or store.
+//   reservoir: p0 = dir.xyz, chosenWeight   p1 = hitPoint.xyz, totWeights   p2 = normal.xyz, totCandidates   p3 = brdf
+//   hit info : p0 = hitPoint.xyz, dst       p1 = normal.xyz, materialIndex  p2 = incomingDir.xyz, uv.x       p3 = uv.y
+struct Planes {
+    float4* p0;
+    float4* p1;
+    float4* p2;
+    float* p3;
+    int64_t count;
+};
+
+struct Tex {
+    float4* rgba;  // RGBA32F textures
+    float* r;      // R32F textures
+    int w, h;
+};
+
+// Mirror of the shader's constants (ReSTIR_BVH_RayTracer.compute:14-66,91-92), snapshotted at dispatch time from
+// the typeless constant table, plus the resolved buffer bindings of the dispatch.  Passed to kernels by value.
+struct KParams {
+    // scene
+    const float4* wide;       // wide BVH nodes, 4 x float4 per BV index
+    const float4* btri;       // baked triangles, 4 x float4 per triangle
+    const rt_bv* BVs; int64_t nBVs;
+    const rt_scene_object* objs; int64_t nObjs;
+    const uint32_t* objRootEntry;  // stack entry of each scene object's mesh-BVH root
+    const rt_light_object* lights; int64_t nLights;
+    const rt_material* mats; int64_t nMats;
+    const rt_triangle* tris; int64_t nTris;
+    const rt_vertex* verts; int64_t nVerts;
+    uint32_t sceneRootEntry;
+    int stackDepth;  // dwords of LDS stack per lane
+    Tex atlas, env;
+    // per-pixel state
+    Planes hit, cand, candB, temporal;
+    Tex result, accumulated, debugOverlay, depth, normals, hitA, hitB;
+    // constants
+    uint32_t MaxBVHDepth;
+    float ScatterProbability;
+    uint32_t MaxBounceCount;
+    int32_t ResX, ResY;
+    float ViewSpaceDimsX, ViewSpaceDimsY, DefocusStrength, FocalPlaneFactor;
+    float camPos[3], lastCamPos[3];
+    float camT[9], lastCamTInv[9];  // row-major 3x3
+    uint32_t FrameRand, FrameCount;
+    int32_t DebugMaxX, DebugMaxY;
+    uint32_t SceneObjectReservoirTestsNum, TriReservoirTestsNum;
+    int32_t ReuseBufferCycle, MaxOffset;
+    uint32_t TemporalCandidatesNum;
+    float SpatialHitPointDiffThreshold, SpatialNormalsAngleThreshold, SpatialBRDFThreshold;
+    float TemporalReuseWeight, PixelMovementThreshold, TemporalPrecisionThreshold;
+    uint32_t EmittingObjectsNum;
+    float atlasDimsX, atlasDimsY, envDimsX, envDimsY;  // raw constant words reinterpreted as float
+    int32_t kwVisReuse, kwWeightRecalc, kwBrdf;
+    int32_t ppFrameCount;
+    // band + instrumentation
+    int32_t row0, row1;
+    unsigned long long* stats;  // 8 counters (rt_dispatch_stats order) or null
+    uint32_t* records;          // 8 dwords per pixel (trace record) or null
+};
+
+// Trace record written when a "TraceRecords" buffer is bound (8 dwords per pixel):
+//   0 triIndex  1 objIndex  2 visitHash  3 lightObj  4 lightTri  5 shadowVisitHash  6 shadowTri  7 bounceVisitHash
+constexpr int RECORD_DWORDS = 8;
+
+}  // namespace rtn

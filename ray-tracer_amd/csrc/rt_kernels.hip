@@ -1,0 +1,926 @@
+// rt_kernels.hip — gfx950 (CDNA4, wave64) kernels of the ReSTIR direct-lighting ray tracer.
+//
+// What each kernel computes follows BVH_ReSTIR_DL/Assets/Scripts/ComputeShaders/ReSTIR_BVH_RayTracer.compute
+// (cited per function as "RS:line"), PreCalc.compute and PostProcessor.compute; how it computes it is specific
+// to this GPU:
+//   * one wave = one 8x8 pixel tile (coherent primary rays), 4 waves per workgroup, workgroups dealt to the
+//     8 XCDs in contiguous runs of tiles so that neighbouring tiles share an L2;
+//   * BVH traversal reads one aligned 64-byte record per internal node (both child boxes + both child stack
+//     entries) and one aligned 64-byte record per triangle; the per-lane traversal stack lives in LDS,
+//     lane-interleaved (conflict-free), one dword per entry, shared by the scene level and the mesh level;
+//   * the reference's InitialTrace is split into a primary-ray kernel and a candidate + shadow-ray kernel;
+//   * per-pixel records are planes of float4 (16-byte coalesced accesses).
+// Arithmetic follows the fp32 conventions documented in include/rt_detmath.h: no contraction
+// (-ffp-contract=off), IEEE divide/sqrt, fixed summation order, so results are bit-identical to the CPU oracle.
+#include "rt_device.h"
+
+#include "../../include/rt_detmath.h"
+
+namespace rtn {
+
+#define DEV __device__ __forceinline__
+
+constexpr float PI_F = 3.1415926f;        // Constants.hlsl:3
+constexpr uint32_t MAX_BVH_DEPTH = 32;    // Constants.hlsl:14
+constexpr int WAVES_PER_BLOCK = 4;
+
+struct v2 { float x, y; };
+struct v3 { float x, y, z; };
+DEV v3 V3(float x, float y, float z) { return {x, y, z}; }
+DEV v3 V3(rt_float3 a) { return {a.x, a.y, a.z}; }
+DEV v3 operator+(v3 a, v3 b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
+DEV v3 operator-(v3 a, v3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
+DEV v3 operator*(v3 a, v3 b) { return {a.x * b.x, a.y * b.y, a.z * b.z}; }
+DEV v3 operator*(v3 a, float s) { return {a.x * s, a.y * s, a.z * s}; }
+DEV v3 operator/(v3 a, float s) { return {a.x / s, a.y / s, a.z / s}; }
+DEV v3 operator-(v3 a) { return {-a.x, -a.y, -a.z}; }
+DEV float dot(v3 a, v3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
+DEV v3 cross(v3 a, v3 b) { return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; }
+DEV float length(v3 a) { return __builtin_sqrtf(dot(a, a)); }
+DEV v3 normalize(v3 a) { float inv = 1.0f / __builtin_sqrtf(dot(a, a)); return a * inv; }
+DEV v3 rcp3(v3 a) { return {1.0f / a.x, 1.0f / a.y, 1.0f / a.z}; }
+// v_min_f32 / v_max_f32 return the non-NaN operand, which is the D3D min/max rule the kernels rely on.
+DEV float fminf_(float a, float b) { return __builtin_fminf(a, b); }
+DEV float fmaxf_(float a, float b) { return __builtin_fmaxf(a, b); }
+DEV float saturate(float x) { return fminf_(fmaxf_(x, 0.0f), 1.0f); }
+DEV float clampf(float x, float lo, float hi) { return fminf_(fmaxf_(x, lo), hi); }
+DEV float sqr(float a) { return a * a; }
+DEV float avg(float a, float b) { return .5f * (a + b); }
+DEV float INF() { return __builtin_inff(); }
+
+// mul(float4x4, float4(v, w)).xyz, column-major storage.
+DEV v3 mul44(const float* m, v3 v, float w) {
+    v3 r;
+    r.x = ((m[0] * v.x + m[4] * v.y) + m[8] * v.z) + m[12] * w;
+    r.y = ((m[1] * v.x + m[5] * v.y) + m[9] * v.z) + m[13] * w;
+    r.z = ((m[2] * v.x + m[6] * v.y) + m[10] * v.z) + m[14] * w;
+    return r;
+}
+DEV v3 mul33(const float* m, v3 v) {
+    return {(m[0] * v.x + m[1] * v.y) + m[2] * v.z, (m[3] * v.x + m[4] * v.y) + m[5] * v.z,
+            (m[6] * v.x + m[7] * v.y) + m[8] * v.z};
+}
+
+// ---------------- RNG (RendererResources.hlsl:63-113) ----------------
+DEV uint32_t NextRandom(uint32_t& state) {
+    state = state * 747796405u + 2891336453u;
+    uint32_t result = ((state >> ((state >> 28) + 4)) ^ state) * 277803737u;
+    result = (result >> 22) ^ result;
+    return result;
+}
+DEV float randNormalized(uint32_t& state) { return (float)NextRandom(state) / 4294967296.0f; }
+DEV int randIntSpan(int a, int b, uint32_t& state) {
+    float randNorm = randNormalized(state);
+    int diff = b - a;
+    int offset = rtdm::f2i((float)diff * randNorm);
+    return a + offset;
+}
+DEV bool weightedRand(float a, float b, uint32_t& state) {
+    float randNorm = randNormalized(state);
+    float relRand = randNorm * b;
+    return relRand < a;
+}
+DEV float randValueNormalDistribution(uint32_t& state) {
+    float theta = 2 * PI_F * randNormalized(state);
+    float rho = __builtin_sqrtf(-2 * rtdm::log_(randNormalized(state)));
+    return rho * rtdm::cos_(theta);
+}
+DEV v3 randPointOnUnitSphere(uint32_t& state) {
+    float x = randValueNormalDistribution(state);
+    float y = randValueNormalDistribution(state);
+    float z = randValueNormalDistribution(state);
+    return normalize(V3(x, y, z));
+}
+DEV v2 randPointInCircle(uint32_t& state) {
+    float angle = randNormalized(state) * 2 * PI_F;
+    float c = rtdm::cos_(angle), s = rtdm::sin_(angle);
+    float r = __builtin_sqrtf(randNormalized(state));
+    return {c * r, s * r};
+}
+DEV float angleBetweenNormals(v3 a, v3 b) {
+    float d = clampf(dot(a, b), -1.0f, 1.0f);
+    return rtdm::acos_(d) * 57.29577951308232f;
+}
+
+// ---------------- BRDF.hlsl (x channel; see the comment on GetBRDF's return type at BRDF.hlsl:25,64) ----------------
+DEV float GetBRDF(v3 incomingDir, v3 outgoingDir, v3 hitNormal, float metallicity, float roughness) {
+    metallicity = 1;
+    incomingDir = -incomingDir;
+    const float hitAlbedoX = 1.0f;
+    v3 H = normalize(incomingDir + outgoingDir);
+    float NdotL = saturate(dot(hitNormal, incomingDir));
+    float NdotV = saturate(dot(hitNormal, outgoingDir));
+    float NdotH = saturate(dot(hitNormal, H));
+    float VdotH = saturate(dot(outgoingDir, H));
+    float F0x = 0.04f + metallicity * (hitAlbedoX - 0.04f);
+    float Fx = F0x + (1.0f - F0x) * rtdm::pow_(1.0f - VdotH, 5.0f);
+    float a = roughness * roughness;
+    float a2 = a * a;
+    float NdotH2 = NdotH * NdotH;
+    float denom = (NdotH2 * (a2 - 1.0f) + 1.0f);
+    float D = a2 / (3.14f * denom * denom);
+    float r = roughness + 1.0f;
+    float k = (r * r) / 8.0f;
+    float G1 = NdotL / (NdotL * (1.0f - k) + k);
+    float G2 = NdotV / (NdotV * (1.0f - k) + k);
+    float G = G1 * G2;
+    float numeratorX = D * G * Fx;
+    float denominator = 4.0f * NdotL * NdotV + 0.001f;
+    float specularX = numeratorX / denominator;
+    float kDx = 1.0f - Fx;
+    kDx *= 1.0f - metallicity;
+    float diffuseX = kDx * hitAlbedoX / 3.14f;
+    return (diffuseX + specularX) * NdotL * 10;
+}
+
+// ---------------- robust loads: out-of-range index -> all-zero element (D3D structured-buffer semantics) ----------------
+DEV rt_material loadMaterial(const KParams& P, int i) {
+    rt_material m;
+    if (i >= 0 && (int64_t)i < P.nMats) m = P.mats[i];
+    else __builtin_memset(&m, 0, sizeof m);
+    return m;
+}
+DEV rt_triangle loadTriangle(const KParams& P, int64_t i) {
+    rt_triangle t;
+    if (i >= 0 && i < P.nTris) t = P.tris[i];
+    else __builtin_memset(&t, 0, sizeof t);
+    return t;
+}
+DEV rt_vertex loadVertex(const KParams& P, int i) {
+    rt_vertex v;
+    if (i >= 0 && (int64_t)i < P.nVerts) v = P.verts[i];
+    else __builtin_memset(&v, 0, sizeof v);
+    return v;
+}
+DEV v3 texLoad(const Tex& t, uint32_t x, uint32_t y) {
+    if (!t.rgba || x >= (uint32_t)t.w || y >= (uint32_t)t.h) return V3(0, 0, 0);
+    float4 c = t.rgba[(int64_t)y * t.w + x];
+    return V3(c.x, c.y, c.z);
+}
+// RS:94-100
+DEV v3 SampleTexture(v2 uv, uint32_t locX, uint32_t locY, uint32_t dimX, uint32_t dimY, const Tex& t) {
+    uint32_t tx = locX + rtdm::f2u(uv.x * (float)dimX);
+    uint32_t ty = locY + rtdm::f2u(uv.y * (float)dimY);
+    return texLoad(t, tx, ty);
+}
+DEV v3 SampleAtlas(const KParams& P, v2 uv, rt_int2 loc, rt_int2 dims) {
+    return SampleTexture(uv, (uint32_t)loc.x, (uint32_t)loc.y, (uint32_t)dims.x, (uint32_t)dims.y, P.atlas);
+}
+DEV float matMetallicity(const KParams& P, const rt_material& m, v2 uv) {
+    return m.metallicity == -1 ? SampleAtlas(P, uv, m.metallicityTexLoc, m.metallicityTexDims).x : m.metallicity;
+}
+DEV float matRoughness(const KParams& P, const rt_material& m, v2 uv) {
+    return m.roughness == -1 ? SampleAtlas(P, uv, m.roughnessTexLoc, m.roughnessTexDims).x : m.roughness;
+}
+DEV v3 matCol(const KParams& P, const rt_material& m, v2 uv) {
+    bool tex = m.col.x == -1 && m.col.y == -1 && m.col.z == -1;
+    return tex ? SampleAtlas(P, uv, m.colTexLoc, m.colTexDims) : V3(m.col);
+}
+
+// ---------------- thread -> pixel mapping ----------------
+// One wave per 8x8 tile.  Workgroup b of the launch runs on XCD (b mod 8) (observed round-robin placement, used
+// for L2 locality only); remap so each XCD gets a contiguous run of workgroups, i.e. a compact image region.
+DEV uint32_t xcdRemap(uint32_t b, uint32_t n) {
+    uint32_t q = n / 8, r = n % 8, xcd = b % 8, k = b / 8;
+    uint32_t base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return base + k;
+}
+struct Pixel { int x, y; bool active; };
+DEV Pixel pixelOfThread(const KParams& P) {
+    // workgroups tile the band as 2x2 groups of 8x8 tiles (16x16 pixels)
+    int bandY0 = P.row0 & ~7;
+    uint32_t gx = (uint32_t)(P.ResX + 15) / 16;
+    uint32_t b = xcdRemap(blockIdx.x, gridDim.x);
+    uint32_t by = b / gx, bx = b % gx;
+    uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    Pixel p;
+    p.x = (int)(bx * 16 + (wave & 1) * 8 + (lane & 7));
+    p.y = bandY0 + (int)(by * 16 + (wave >> 1) * 8 + (lane >> 3));
+    p.active = p.x < P.ResX && p.y < P.ResY && p.y >= P.row0 && p.y < P.row1;
+    return p;
+}
+
+// ---------------- BVH traversal ----------------
+struct Trav {
+    float dst;        // closest hit distance along the world ray, INF on a miss
+    float u, v;       // barycentrics of the closest hit
+    int tri, obj;     // closest-hit triangle and scene object, -1 on a miss
+    int triChecks, bvChecks;  // debugData of RS:184,202,265,267
+    // instrumentation (INSTR only)
+    uint32_t hash;
+    uint32_t pops, objVisits, triIters;
+};
+
+DEV float RayBVIntersect(v3 pos, v3 inv, v3 bmin, v3 bmax) {  // RS:148-161
+    v3 tMin = (bmin - pos) * inv;
+    v3 tMax = (bmax - pos) * inv;
+    v3 t1 = {fminf_(tMin.x, tMax.x), fminf_(tMin.y, tMax.y), fminf_(tMin.z, tMax.z)};
+    v3 t2 = {fmaxf_(tMin.x, tMax.x), fmaxf_(tMin.y, tMax.y), fmaxf_(tMin.z, tMax.z)};
+    float tNear = fmaxf_(fmaxf_(t1.x, t1.y), t1.z);
+    float tFar = fminf_(fminf_(t2.x, t2.y), t2.z);
+    bool didHit = tFar >= tNear && tFar > 0;
+    return didHit ? (tNear > 0 ? tNear : 0.0f) : INF();
+}
+
+// GetRayCollision (RS:284-291) = TraverseSceneBVH (RS:219-282) + TraverseTrisBVH (RS:163-217), as one loop over
+// one stack.  `stk` points at this lane's column of the LDS stack (entries 64 dwords apart).  Visit order, the
+// near-first push rule and the strict `<` culls are the reference's; only what is fetched per step differs.
+// Shading data of the winning triangle (uv, normals, hit point) is derived afterwards from (tri, obj, u, v).
+template <bool INSTR>
+DEV void traverse(const KParams& P, const v3 wpos, const v3 wdir, const v3 winv, uint32_t* stk, Trav& t) {
+    v3 rpos = wpos, rdir = wdir, rinv = winv;
+    float best = INF();       // hitInfo.dst of the level being traversed (world level / object level)
+    float worldBest = INF();
+    int sp = 0, objBase = -1, objCur = 0, objEnd = 0, curObj = -1, localTri = -1;
+    float localU = 0, localV = 0;
+    t.tri = -1; t.obj = -1; t.u = 0; t.v = 0; t.triChecks = 0; t.bvChecks = 0;
+    if (INSTR) { t.hash = 2166136261u; t.pops = 0; t.objVisits = 0; t.triIters = 0; }
+    const int cap = P.stackDepth;
+    stk[0] = P.sceneRootEntry;
+    sp = 1;
+    for (;;) {
+        if (objBase < 0) {
+            if (objCur < objEnd) {
+                // next scene object of the current scene-level leaf (RS:235-246)
+                const rt_scene_object* o = &P.objs[objCur];
+                const float* m = o->worldToLocalMatrix.m;
+                rpos = mul44(m, wpos, 1.0f);
+                rdir = mul44(m, wdir, 0.0f);
+                rinv = rcp3(rdir);
+                best = INF();
+                localTri = -1;
+                curObj = objCur;
+                objBase = sp;
+                if (sp < cap) stk[sp * 64] = P.objRootEntry[objCur];
+                sp++;
+                objCur++;
+                if (INSTR) t.objVisits++;
+                continue;
+            }
+            if (sp == 0) break;
+        } else if (sp == objBase) {
+            // the object's tree is exhausted (RS:251-258)
+            if (best < worldBest) { worldBest = best; t.tri = localTri; t.obj = curObj; t.u = localU; t.v = localV; }
+            best = worldBest;
+            rpos = wpos; rdir = wdir; rinv = winv;
+            objBase = -1;
+            continue;
+        }
+        --sp;
+        const uint32_t e = sp < cap ? stk[sp * 64] : (ENTRY_LEAF);  // overflowed pushes pop as empty leaves
+        if (INSTR) t.pops++;
+        if (e & (ENTRY_LEAF | ENTRY_LEAF_INDIRECT)) {
+            int start, count;
+            if (e & ENTRY_LEAF) {
+                start = (int)(e & (uint32_t)ENTRY_INLINE_MAX_START);
+                count = (int)((e >> 26) & 31u);
+                if (INSTR) { t.hash = (t.hash ^ (uint32_t)start) * 16777619u; t.hash = (t.hash ^ (uint32_t)count) * 16777619u; }
+            } else {
+                const rt_bv* bv = &P.BVs[e & ENTRY_INDEX_MASK];
+                int a = bv->indexA, b = bv->indexB;
+                if (INSTR) { t.hash = (t.hash ^ (uint32_t)a) * 16777619u; t.hash = (t.hash ^ (uint32_t)b) * 16777619u; }
+                start = a < 0 ? -a : a;
+                count = b < 0 ? -b : b;
+            }
+            if (objBase < 0) {  // scene-level leaf: a run of scene objects
+                objCur = start;
+                objEnd = start + count;
+                continue;
+            }
+            for (int triIndex = start; triIndex < start + count; triIndex++) {  // RS:179-193
+                const float4* rec = P.btri + (int64_t)triIndex * 4;
+                const float4 q3 = rec[3];
+                if (INSTR) t.triIters++;
+                if (dot(V3(q3.x, q3.y, q3.z), rdir) <= 0) {
+                    const float4 q0 = rec[0], q1 = rec[1], q2 = rec[2];
+                    // RayTriangleIntersect, RS:119-146
+                    v3 edgeAB = V3(q1.x, q1.y, q1.z), edgeAC = V3(q2.x, q2.y, q2.z);
+                    v3 normalVector = V3(q0.w, q1.w, q2.w);
+                    v3 ao = rpos - V3(q0.x, q0.y, q0.z);
+                    v3 dao = cross(ao, rdir);
+                    float determinant = -dot(rdir, normalVector);
+                    float invDet = 1 / determinant;
+                    float dst = dot(ao, normalVector) * invDet;
+                    float u = dot(edgeAC, dao) * invDet;
+                    float v = -dot(edgeAB, dao) * invDet;
+                    float w = 1 - u - v;
+                    bool didHit = determinant >= 1E-8f && dst >= 0 && u >= 0 && v >= 0 && w >= 0;
+                    t.triChecks++;
+                    if (didHit && dst < best) { best = dst; localU = u; localV = v; localTri = triIndex; }
+                }
+            }
+        } else {
+            const float4* rec = P.wide + (int64_t)e * 4;
+            const float4 q0 = rec[0], q1 = rec[1], q2 = rec[2], q3 = rec[3];
+            if (INSTR) t.hash = (t.hash ^ (0x80000000u | e)) * 16777619u;
+            float dstA = RayBVIntersect(rpos, rinv, V3(q0.x, q0.y, q0.z), V3(q0.w, q1.x, q1.y));
+            float dstB = RayBVIntersect(rpos, rinv, V3(q1.z, q1.w, q2.x), V3(q2.y, q2.z, q2.w));
+            t.bvChecks += 2;
+            const uint32_t eA = __float_as_uint(q3.x), eB = __float_as_uint(q3.y);
+            // push the nearer child last so it is visited first (RS:204-214)
+            const bool aFirst = dstA < dstB;
+            const uint32_t e1 = aFirst ? eB : eA, e2 = aFirst ? eA : eB;
+            const float d1 = aFirst ? dstB : dstA, d2 = aFirst ? dstA : dstB;
+            if (d1 < best) { if (sp < cap) stk[sp * 64] = e1; sp++; }
+            if (d2 < best) { if (sp < cap) stk[sp * 64] = e2; sp++; }
+        }
+    }
+    t.dst = worldBest;
+}
+
+// Shading data of a traversal result, as TraverseSceneBVH leaves it in hitInfo (RS:248-258).
+struct HitInfo { float dst; v3 hitPoint; v2 uv; v3 normal; v3 incomingDir; int materialIndex; };
+DEV HitInfo resolveHit(const KParams& P, const Trav& t, v3 wpos, v3 wdir) {
+    HitInfo h;
+    h.dst = t.dst;
+    h.hitPoint = V3(-1, -1, -1);
+    h.uv = {0, 0};
+    h.normal = V3(0, 0, 0);
+    h.incomingDir = V3(0, 0, 0);
+    h.materialIndex = 0;
+    if (t.tri >= 0) {
+        const rt_scene_object* o = &P.objs[t.obj];
+        const rt_triangle tri = P.tris[t.tri];
+        const rt_float2 uv0 = P.verts[tri.vertex0Index].uv, uv1 = P.verts[tri.vertex1Index].uv,
+                        uv2 = P.verts[tri.vertex2Index].uv;
+        float w = 1 - t.u - t.v;
+        h.uv.x = (uv0.x * w + uv1.x * t.u) + uv2.x * t.v;
+        h.uv.y = (uv0.y * w + uv1.y * t.u) + uv2.y * t.v;
+        v3 n = V3(tri.localNormal);
+        const int matIndex = o->materialIndex;
+        rt_material mat = loadMaterial(P, matIndex);
+        if (mat.normalsTexLoc.x != -1 && mat.normalsTexLoc.y != -1)
+            n = SampleAtlas(P, h.uv, mat.normalsTexLoc, mat.normalsTexDims) * 2 - V3(1, 1, 1);
+        h.normal = normalize(mul44(o->localToWorldMatrix.m, n, 0.0f));
+        h.hitPoint = wpos + wdir * t.dst;
+        h.materialIndex = matIndex;
+    }
+    return h;
+}
+
+// ---------------- wave-level counters ----------------
+DEV void waveAdd(unsigned long long* dst, uint32_t v) {
+    // butterfly sum over the 64 lanes (inactive lanes contribute their own v, so callers pass 0 for them)
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    if ((threadIdx.x & 63) == 0 && v) atomicAdd(dst, (unsigned long long)v);
+}
+enum { ST_RAYS = 0, ST_POPS, ST_BVCHECKS, ST_OBJVISITS, ST_TRIITERS, ST_TRICHECKS, ST_NEIGHBOURS, ST_ACTIVE };
+
+DEV uint32_t* laneStack(uint32_t* lds, int depth) {
+    uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    return lds + (size_t)wave * depth * 64 + lane;
+}
+
+DEV void storeHit(const KParams& P, int64_t i, const HitInfo& h) {
+    P.hit.p0[i] = make_float4(h.hitPoint.x, h.hitPoint.y, h.hitPoint.z, h.dst);
+    P.hit.p1[i] = make_float4(h.normal.x, h.normal.y, h.normal.z, __int_as_float(h.materialIndex));
+    P.hit.p2[i] = make_float4(h.incomingDir.x, h.incomingDir.y, h.incomingDir.z, h.uv.x);
+    P.hit.p3[i] = h.uv.y;
+}
+DEV HitInfo loadHit(const KParams& P, int64_t i) {
+    float4 a = P.hit.p0[i], b = P.hit.p1[i], c = P.hit.p2[i];
+    HitInfo h;
+    h.dst = a.w; h.hitPoint = V3(a.x, a.y, a.z);
+    h.normal = V3(b.x, b.y, b.z); h.materialIndex = __float_as_int(b.w);
+    h.incomingDir = V3(c.x, c.y, c.z); h.uv = {c.w, P.hit.p3[i]};
+    return h;
+}
+struct Reservoir { v3 dir, hitPoint, normal; float brdf, chosenWeight, totWeights, totCandidates; };
+DEV Reservoir emptyReservoir() {
+    Reservoir r;
+    r.dir = r.hitPoint = r.normal = V3(0, 0, 0);
+    r.brdf = r.chosenWeight = r.totWeights = r.totCandidates = 0;
+    return r;
+}
+DEV void storeReservoir(const Planes& pl, int64_t i, const Reservoir& r) {
+    pl.p0[i] = make_float4(r.dir.x, r.dir.y, r.dir.z, r.chosenWeight);
+    pl.p1[i] = make_float4(r.hitPoint.x, r.hitPoint.y, r.hitPoint.z, r.totWeights);
+    pl.p2[i] = make_float4(r.normal.x, r.normal.y, r.normal.z, r.totCandidates);
+    pl.p3[i] = r.brdf;
+}
+// index beyond the buffer -> zero reservoir
+DEV Reservoir loadReservoir(const Planes& pl, int64_t i) {
+    if (i < 0 || i >= pl.count) return emptyReservoir();
+    float4 a = pl.p0[i], b = pl.p1[i], c = pl.p2[i];
+    Reservoir r;
+    r.dir = V3(a.x, a.y, a.z); r.chosenWeight = a.w;
+    r.hitPoint = V3(b.x, b.y, b.z); r.totWeights = b.w;
+    r.normal = V3(c.x, c.y, c.z); r.totCandidates = c.w;
+    r.brdf = pl.p3[i];
+    return r;
+}
+DEV float depthAt(const KParams& P, int x, int y) {
+    if (x < 0 || y < 0 || x >= P.ResX || y >= P.ResY) return 0.0f;
+    return P.depth.r[(int64_t)y * P.ResX + x];
+}
+DEV v3 GetFocalPos(const KParams& P, v2 uv) {  // RS:441-449
+    float focalPosX = (uv.x - 0.5f) * 2.0f * P.ViewSpaceDimsX;
+    float focalPosY = (uv.y - 0.5f) * 2.0f * P.ViewSpaceDimsY;
+    v3 focalPos = V3(focalPosX, focalPosY, 1) * P.FocalPlaneFactor;
+    return mul33(P.camT, focalPos) + V3(P.camPos[0], P.camPos[1], P.camPos[2]);
+}
+DEV v2 GetLastUV(const KParams& P, v3 worldFocalPos) {  // RS:451-461
+    v3 focalPos = worldFocalPos - V3(P.lastCamPos[0], P.lastCamPos[1], P.lastCamPos[2]);
+    v3 cameraFocalPos = mul33(P.lastCamTInv, focalPos);
+    v3 ndc = cameraFocalPos / P.FocalPlaneFactor;
+    float uvX = (ndc.x / (2.0f * P.ViewSpaceDimsX)) + 0.5f;
+    float uvY = (ndc.y / (2.0f * P.ViewSpaceDimsY)) + 0.5f;
+    return {clampf(uvX, 0.0f, 1.0f), clampf(uvY, 0.0f, 1.0f)};
+}
+
+// =====================================================================================================
+// InitialTrace, first half (RS:463-491,496-509): camera ray, closest hit, G-buffer outputs.
+// =====================================================================================================
+template <bool INSTR>
+__global__ __launch_bounds__(256) void k_primary(const KParams P) {
+    extern __shared__ uint32_t lds[];
+    const Pixel px = pixelOfThread(P);
+    uint32_t rays = 0;
+    Trav t;
+    if (INSTR) { t.pops = t.objVisits = t.triIters = 0; t.triChecks = t.bvChecks = 0; }
+    if (px.active) {
+        const uint32_t idx = (uint32_t)px.x, idy = (uint32_t)px.y;
+        uint32_t state = idy * (uint32_t)P.ResX + idx + P.FrameRand;
+        v2 uv = {(float)idx / (float)P.ResX, (float)idy / (float)P.ResY};
+        v3 worldFocalPos = GetFocalPos(P, uv);
+        v2 c = randPointInCircle(state);
+        c.x *= P.DefocusStrength; c.y *= P.DefocusStrength;
+        v3 jitter = mul33(P.camT, V3(c.x, c.y, 0));
+        v3 rpos = V3(P.camPos[0], P.camPos[1], P.camPos[2]) + jitter * P.FocalPlaneFactor;
+        v3 rdir = normalize(worldFocalPos - rpos);
+
+        traverse<INSTR>(P, rpos, rdir, rcp3(rdir), laneStack(lds, P.stackDepth), t);
+        rays = 1;
+        HitInfo h = resolveHit(P, t, rpos, rdir);
+        const bool didHit = h.dst != INF();
+        h.incomingDir = rdir;
+        rt_material material = loadMaterial(P, h.materialIndex);
+        float bump = material.bump == -1 ? SampleAtlas(P, h.uv, material.bumpTexLoc, material.bumpTexDims).x : material.bump;
+        h.hitPoint = h.hitPoint - h.incomingDir * bump;
+
+        const int64_t i = (int64_t)idy * P.ResX + idx;
+        storeHit(P, i, h);
+        const bool badMaxBVHDepth = P.MaxBVHDepth > MAX_BVH_DEPTH;
+        P.debugOverlay.rgba[i] = make_float4(t.triChecks / (float)P.DebugMaxX, t.bvChecks / (float)P.DebugMaxY,
+                                             badMaxBVHDepth ? 1.0f : 0.0f, 0.0f);
+        P.depth.r[i] = h.dst;
+        P.normals.rgba[i] = make_float4((h.normal.x + 1) * 0.5f, (h.normal.y + 1) * 0.5f, (h.normal.z + 1) * 0.5f, 0.0f);
+        v3 firstHit = didHit ? h.hitPoint : V3(0, 0, 0);
+        float4 fh = make_float4(firstHit.x, firstHit.y, firstHit.z, 0.0f);
+        if (P.FrameCount % 2 == 0) P.hitA.rgba[i] = fh; else P.hitB.rgba[i] = fh;
+        if (INSTR && P.records) {
+            uint32_t* r = P.records + i * RECORD_DWORDS;
+            r[0] = (uint32_t)t.tri; r[1] = (uint32_t)t.obj; r[2] = t.hash; r[3] = 0xffffffffu; r[4] = 0xffffffffu;
+            r[5] = 0; r[6] = 0xffffffffu; r[7] = 0;
+        }
+    }
+    if (P.stats) {
+        waveAdd(P.stats + ST_RAYS, rays);
+        waveAdd(P.stats + ST_ACTIVE, px.active ? 1u : 0u);
+        if (INSTR) {
+            waveAdd(P.stats + ST_POPS, px.active ? t.pops : 0);
+            waveAdd(P.stats + ST_BVCHECKS, px.active ? (uint32_t)t.bvChecks : 0);
+            waveAdd(P.stats + ST_OBJVISITS, px.active ? t.objVisits : 0);
+            waveAdd(P.stats + ST_TRIITERS, px.active ? t.triIters : 0);
+            waveAdd(P.stats + ST_TRICHECKS, px.active ? (uint32_t)t.triChecks : 0);
+        }
+    }
+}
+
+// =====================================================================================================
+// InitialTrace, second half (RS:494 -> GenerateCandidatesDL, RS:385-434): one RIS light sample per hit pixel
+// and, under VIS_REUSE, its shadow ray.
+// =====================================================================================================
+DEV int LightObjectReservoirSample(const KParams& P, uint32_t& state) {  // RS:293-313
+    auto area = [&](int i) { return (i >= 0 && (int64_t)i < P.nLights) ? P.lights[i].areaApprox : 0.0f; };
+    int firstIndex = randIntSpan(0, (int)P.EmittingObjectsNum, state);
+    int chosenIndex = firstIndex;
+    float totWeights = area(firstIndex);
+    for (uint32_t i = 0; i < P.SceneObjectReservoirTestsNum; i++) {
+        int candidateIndex = randIntSpan(0, (int)P.EmittingObjectsNum, state);
+        float candidateWeight = area(candidateIndex);
+        if (weightedRand(candidateWeight, totWeights, state)) chosenIndex = candidateIndex;
+        totWeights += candidateWeight;
+    }
+    return chosenIndex;
+}
+DEV int TriReservoirSample(const KParams& P, uint32_t startTriIndex, uint32_t endTriIndex, uint32_t& state) {  // RS:328-348
+    auto area = [&](int i) { return (i >= 0 && (int64_t)i < P.nTris) ? P.tris[i].area : 0.0f; };
+    int firstIndex = randIntSpan((int)startTriIndex, (int)endTriIndex, state);
+    int chosenIndex = firstIndex;
+    float totWeights = area(firstIndex);
+    for (uint32_t i = 0; i < P.TriReservoirTestsNum; i++) {
+        int candidateIndex = randIntSpan((int)startTriIndex, (int)endTriIndex, state);
+        float candidateWeight = area(candidateIndex);
+        if (weightedRand(candidateWeight, totWeights, state)) chosenIndex = candidateIndex;
+        totWeights += candidateWeight;
+    }
+    return chosenIndex;
+}
+DEV v2 GenerateCandidateWeight(const KParams& P, float sqrDst, float hitAngleDot, v3 incomingDir, v3 outgoingDir,
+                               v3 hitNormal, float metallicity, float roughness, float brightness) {  // RS:351-360
+    float weight = brightness * hitAngleDot / sqrDst;
+    float brdf = 1.0f;
+    if (P.kwBrdf) {
+        brdf = GetBRDF(incomingDir, outgoingDir, hitNormal, metallicity, roughness);
+        weight *= brdf;
+    }
+    return {weight, brdf};
+}
+
+template <bool INSTR>
+__global__ __launch_bounds__(256) void k_candidates(const KParams P) {
+    extern __shared__ uint32_t lds[];
+    const Pixel px = pixelOfThread(P);
+    uint32_t rays = 0;
+    Trav t;
+    if (INSTR) { t.pops = t.objVisits = t.triIters = 0; t.triChecks = t.bvChecks = 0; }
+    if (px.active) {
+        const uint32_t idx = (uint32_t)px.x, idy = (uint32_t)px.y;
+        const int64_t i = (int64_t)idy * P.ResX + idx;
+        const HitInfo hitInfo = loadHit(P, i);
+        if (hitInfo.dst != INF()) {
+            // the two draws of randPointInCircle precede this in the reference's single kernel
+            uint32_t state = idy * (uint32_t)P.ResX + idx + P.FrameRand;
+            NextRandom(state);
+            NextRandom(state);
+            const uint32_t pixelIndex = (uint32_t)P.ResX * idy + idx;
+
+            uint32_t lightObjectIndex = (uint32_t)LightObjectReservoirSample(P, state);
+            rt_light_object lightObject;
+            if ((int64_t)lightObjectIndex < P.nLights) lightObject = P.lights[lightObjectIndex];
+            else __builtin_memset(&lightObject, 0, sizeof lightObject);
+            uint32_t startTriIndex = (uint32_t)lightObject.triStart;
+            uint32_t endTriIndex = (uint32_t)(lightObject.triStart + lightObject.totTris);
+            uint32_t triIndex = (uint32_t)TriReservoirSample(P, startTriIndex, endTriIndex, state);
+            if (INSTR && P.records) { P.records[i * RECORD_DWORDS + 3] = lightObjectIndex; P.records[i * RECORD_DWORDS + 4] = triIndex; }
+            rt_triangle tri = loadTriangle(P, (int64_t)triIndex);
+            // GetRandWorldPointTri, RS:362-383
+            v3 v0 = V3(loadVertex(P, tri.vertex0Index).pos), v1 = V3(loadVertex(P, tri.vertex1Index).pos),
+               v2_ = V3(loadVertex(P, tri.vertex2Index).pos);
+            float r1 = randNormalized(state);
+            float r2 = randNormalized(state);
+            if (r1 + r2 > 1.0f) { r1 = 1.0f - r1; r2 = 1.0f - r2; }
+            v3 localPoint = v0 * (1.0f - r1 - r2) + v1 * r1 + v2_ * r2;
+            v3 worldPoint = mul44(lightObject.localToWorldMatrix.m, localPoint, 1.0f);
+
+            v3 dst = worldPoint - hitInfo.hitPoint;
+            v3 dir = normalize(dst);
+            Reservoir res;
+            if (dot(hitInfo.normal, dir) < 0) {
+                res = emptyReservoir();
+            } else {
+                v3 worldNormal = normalize(mul44(lightObject.localToWorldMatrix.m, V3(tri.localNormal), 0.0f));
+                float hitAngleDot = fmaxf_(dot(worldNormal, dir), 0);
+                float sqrDst = dot(dst, dst);
+                rt_material material = loadMaterial(P, hitInfo.materialIndex);
+                float metallicity = matMetallicity(P, material, hitInfo.uv);
+                float roughness = matRoughness(P, material, hitInfo.uv);
+                v2 wb = GenerateCandidateWeight(P, sqrDst, hitAngleDot, hitInfo.incomingDir, dir, hitInfo.normal,
+                                                metallicity, roughness, lightObject.brightness);
+                if (P.kwVisReuse) {  // RS:422-430
+                    traverse<INSTR>(P, hitInfo.hitPoint, dir, rcp3(dir), laneStack(lds, P.stackDepth), t);
+                    rays = 1;
+                    int shadowMat = t.obj >= 0 ? P.objs[t.obj].materialIndex : 0;
+                    if (loadMaterial(P, shadowMat).brightness == 0) wb.x = 0;
+                    if (INSTR && P.records) { P.records[i * RECORD_DWORDS + 5] = t.hash; P.records[i * RECORD_DWORDS + 6] = (uint32_t)t.tri; }
+                }
+                res.dir = dir; res.hitPoint = hitInfo.hitPoint; res.normal = hitInfo.normal;
+                res.brdf = wb.y; res.chosenWeight = wb.x; res.totWeights = wb.x; res.totCandidates = 1;
+            }
+            if ((int64_t)pixelIndex < P.cand.count) storeReservoir(P.cand, pixelIndex, res);
+        }
+    }
+    if (P.stats) {
+        waveAdd(P.stats + ST_RAYS, rays);
+        if (INSTR) {
+            waveAdd(P.stats + ST_POPS, rays ? t.pops : 0);
+            waveAdd(P.stats + ST_BVCHECKS, rays ? (uint32_t)t.bvChecks : 0);
+            waveAdd(P.stats + ST_OBJVISITS, rays ? t.objVisits : 0);
+            waveAdd(P.stats + ST_TRIITERS, rays ? t.triIters : 0);
+            waveAdd(P.stats + ST_TRICHECKS, rays ? (uint32_t)t.triChecks : 0);
+        }
+    }
+}
+
+// =====================================================================================================
+// TemporalReuse (RS:586-641)
+// =====================================================================================================
+__global__ __launch_bounds__(256) void k_temporal(const KParams P) {
+    const Pixel px = pixelOfThread(P);
+    bool active = px.active && P.FrameCount != 0;
+    if (active) active = depthAt(P, px.x, px.y) != INF();
+    if (active) {
+        const uint32_t idx = (uint32_t)px.x, idy = (uint32_t)px.y;
+        uint32_t state = idy * (uint32_t)P.ResX + idx + P.FrameRand;
+        const uint32_t pixelIndex = (uint32_t)P.ResX * idy + idx;
+        v2 uv = {(float)idx / (float)P.ResX, (float)idy / (float)P.ResY};
+        v3 worldFocalPos = GetFocalPos(P, uv);
+        v2 lastUV = GetLastUV(P, worldFocalPos);
+        float dx = uv.x - lastUV.x, dy = uv.y - lastUV.y;
+        Reservoir thisFrame = loadReservoir(P.cand, pixelIndex);
+        if (__builtin_sqrtf(dx * dx + dy * dy) > P.TemporalPrecisionThreshold) {
+            storeReservoir(P.temporal, pixelIndex, thisFrame);
+        } else {
+            const int64_t i = (int64_t)idy * P.ResX + idx;
+            float4 a = P.hitA.rgba[i], b = P.hitB.rgba[i];
+            float movement = length(V3(a.x, a.y, a.z) - V3(b.x, b.y, b.z));
+            if (movement <= P.PixelMovementThreshold) {
+                Reservoir last = loadReservoir(P.temporal, pixelIndex);
+                float adjustedThis = thisFrame.totWeights * (1.0f - P.TemporalReuseWeight);
+                float adjustedLast = last.totWeights * P.TemporalReuseWeight;
+                float totWeights = adjustedThis + adjustedLast;
+                if (weightedRand(adjustedLast, totWeights, state)) {
+                    thisFrame.dir = last.dir;
+                    thisFrame.chosenWeight = last.chosenWeight;
+                    thisFrame.hitPoint = last.hitPoint;
+                }
+                thisFrame.totWeights = avg(thisFrame.totWeights * (1.0f - P.TemporalReuseWeight), last.totWeights * P.TemporalReuseWeight);
+                thisFrame.totCandidates = avg(thisFrame.totCandidates * (1.0f - P.TemporalReuseWeight), last.totCandidates * P.TemporalReuseWeight);
+            }
+            storeReservoir(P.cand, pixelIndex, thisFrame);
+            storeReservoir(P.temporal, pixelIndex, thisFrame);
+        }
+    }
+    if (P.stats) waveAdd(P.stats + ST_ACTIVE, active ? 1u : 0u);
+}
+
+// =====================================================================================================
+// SpatialReusePass (RS:514-571)
+// =====================================================================================================
+__global__ __launch_bounds__(256) void k_spatial(const KParams P) {
+    const Pixel px = pixelOfThread(P);
+    bool active = px.active;
+    if (active) active = depthAt(P, px.x, px.y) != INF();
+    uint32_t neighbours = 0;
+    if (active) {
+        const uint32_t idx = (uint32_t)px.x, idy = (uint32_t)px.y;
+        uint32_t state = idy * (uint32_t)P.ResX + idx + P.FrameRand;
+        const uint32_t pixelBaseIndex = (uint32_t)P.ResX * idy + idx;
+        const Planes& src = P.ReuseBufferCycle ? P.cand : P.candB;
+        const Planes& dstb = P.ReuseBufferCycle ? P.candB : P.cand;
+        const Reservoir base = loadReservoir(src, pixelBaseIndex);
+        Reservoir sp = base;
+        for (uint32_t k = 0; k < P.TemporalCandidatesNum; k++) {
+            int ox = rtdm::f2i((float)randIntSpan(-P.MaxOffset, P.MaxOffset, state));
+            int oy = rtdm::f2i((float)randIntSpan(-P.MaxOffset, P.MaxOffset, state));
+            int offX = px.x + ox, offY = px.y + oy;
+            // `any(offsetID) < 0` (RS:528) is always false: negative coordinates are not rejected; a negative x
+            // wraps into the previous row through the unsigned pixel index, a negative y indexes out of range.
+            if (offX >= P.ResX || offY >= P.ResY || depthAt(P, offX, offY) == INF()) continue;
+            uint32_t pixelIndex = (uint32_t)P.ResX * (uint32_t)offY + (uint32_t)offX;
+            const Reservoir cand = loadReservoir(src, (int64_t)pixelIndex);
+            neighbours++;
+            if (cand.dir.x == 0 || cand.dir.y == 0 || cand.dir.z == 0) continue;  // `all(dir) == 0`, RS:536
+            float hitPointDiff = length(base.hitPoint - cand.hitPoint);
+            float normalDiffDeg = angleBetweenNormals(base.normal, cand.normal);
+            if (hitPointDiff > P.SpatialHitPointDiffThreshold || normalDiffDeg > P.SpatialNormalsAngleThreshold ||
+                rtdm::fabs_(sp.brdf - cand.brdf) > P.SpatialBRDFThreshold)
+                continue;
+            if (weightedRand(cand.chosenWeight, sp.totWeights, state)) {
+                sp.dir = cand.dir; sp.chosenWeight = cand.chosenWeight; sp.hitPoint = cand.hitPoint;
+                sp.normal = cand.normal; sp.brdf = cand.brdf;
+            }
+            sp.totWeights += cand.totWeights;
+            sp.totCandidates += cand.totCandidates;
+        }
+        storeReservoir(dstb, pixelBaseIndex, sp);
+    }
+    if (P.stats) { waveAdd(P.stats + ST_ACTIVE, active ? 1u : 0u); waveAdd(P.stats + ST_NEIGHBOURS, neighbours); }
+}
+
+// TransferToOriginal (RS:575-582)
+__global__ __launch_bounds__(256) void k_transfer(const KParams P) {
+    const Pixel px = pixelOfThread(P);
+    bool active = px.active;
+    if (active) active = depthAt(P, px.x, px.y) != INF();
+    if (active) {
+        const int64_t i = (int64_t)((uint32_t)P.ResX * (uint32_t)px.y + (uint32_t)px.x);
+        P.cand.p0[i] = P.candB.p0[i];
+        P.cand.p1[i] = P.candB.p1[i];
+        P.cand.p2[i] = P.candB.p2[i];
+        P.cand.p3[i] = P.candB.p3[i];
+    }
+    if (P.stats) waveAdd(P.stats + ST_ACTIVE, active ? 1u : 0u);
+}
+
+// =====================================================================================================
+// TraceRays (RS:645-815)
+// =====================================================================================================
+DEV v3 SampleEnvironmentMap(const KParams& P, v3 dir) {  // RS:102-117
+    dir = -dir;
+    float theta = rtdm::atan2_(dir.z, dir.x);
+    float phi = rtdm::asin_(dir.y);
+    float u = (theta / (2.0f * PI_F)) + 0.5f;
+    float v = 0.5f - (phi / PI_F);
+    return SampleTexture({u, v}, 0, 0, rtdm::f2u(P.envDimsX), rtdm::f2u(P.envDimsY), P.env);
+}
+
+template <bool INSTR>
+__global__ __launch_bounds__(256) void k_trace_rays(const KParams P) {
+    extern __shared__ uint32_t lds[];
+    const Pixel px = pixelOfThread(P);
+    uint32_t rays = 0, pops = 0, bvc = 0, objv = 0, trii = 0, tric = 0;
+    if (px.active) {
+        const uint32_t idx = (uint32_t)px.x, idy = (uint32_t)px.y;
+        uint32_t state = idy * (uint32_t)P.ResX + idx + P.FrameRand;
+        const uint32_t pixelIndex = (uint32_t)P.ResX * idy + idx;
+        const int64_t i = (int64_t)idy * P.ResX + idx;
+        HitInfo hitInfo = loadHit(P, i);
+        const Reservoir cr = loadReservoir(P.cand, pixelIndex);
+        if (hitInfo.dst == INF()) {
+            v3 col = SampleEnvironmentMap(P, hitInfo.incomingDir);
+            P.result.rgba[i] = make_float4(col.x, col.y, col.z, 0.0f);
+        } else if ((cr.dir.x == 0 || cr.dir.y == 0 || cr.dir.z == 0) || dot(hitInfo.normal, cr.dir) < 0) {
+            rt_material material = loadMaterial(P, hitInfo.materialIndex);
+            v3 col = matCol(P, material, hitInfo.uv) * material.brightness / sqr(hitInfo.dst);
+            P.result.rgba[i] = make_float4(col.x, col.y, col.z, 0.0f);
+        } else {
+            // Trace, RS:710-757.  ray.pos stays the primary hit point for every bounce, as in the reference.
+            const v3 rpos = hitInfo.hitPoint;
+            v3 rdir = cr.dir;
+            const v3 rinv = rcp3(cr.dir);  // never refreshed: bounces beyond the first reuse it (RS:735,753)
+            float totTravelDst = 0;
+            float rc = dot(hitInfo.normal, rdir);
+            v3 rayColor = V3(rc, rc, rc), directLight = V3(0, 0, 0), indirectLight = V3(0, 0, 0);
+            v3 incomingDir = hitInfo.incomingDir;
+            uint32_t hash = 2166136261u;
+            for (uint32_t bounceCount = 0; bounceCount <= P.MaxBounceCount; bounceCount++) {
+                if (hitInfo.dst == INF()) break;
+                rt_material material = loadMaterial(P, hitInfo.materialIndex);
+                bool invalid = (bounceCount == 1 && material.brightness <= 0) ||
+                               (bounceCount == 0 && dot(hitInfo.normal, rdir) < 0);
+                if (invalid) storeReservoir(P.cand, pixelIndex, emptyReservoir());
+                float metallicity = matMetallicity(P, material, hitInfo.uv);
+                float roughness = matRoughness(P, material, hitInfo.uv);
+                if (bounceCount != 0) {
+                    incomingDir = rdir;
+                    (void)randNormalized(state);  // isSpecularBounce draw (RS:734); the flag itself is unused
+                    v3 newDir = normalize(hitInfo.normal + randPointOnUnitSphere(state));
+                    if (dot(hitInfo.normal, newDir) < 0) newDir = -newDir;
+                    rdir = newDir;
+                    if (P.kwWeightRecalc && bounceCount == 1 && material.brightness > 0) {  // RS:645-657
+                        v2 wb = GenerateCandidateWeight(P, sqr(hitInfo.dst), fmaxf_(dot(hitInfo.normal, rdir), 0),
+                                                        incomingDir, rdir, hitInfo.normal, metallicity, roughness,
+                                                        material.brightness);
+                        P.temporal.p0[pixelIndex].w = wb.x;
+                        P.temporal.p3[pixelIndex] = wb.y;
+                    }
+                }
+                v3 col = matCol(P, material, hitInfo.uv);
+                v3 emittedLight = col * material.brightness / sqr(hitInfo.dst);
+                v3 rayColFactor = col;
+                if (P.kwBrdf) rayColFactor = rayColFactor * GetBRDF(incomingDir, rdir, hitInfo.normal, metallicity, roughness);
+                rayColor = rayColor * rayColFactor;
+                totTravelDst += hitInfo.dst;
+                if (bounceCount == 0) directLight = directLight + emittedLight * rayColor;
+                else indirectLight = indirectLight + emittedLight * rayColor;
+                if (bounceCount != P.MaxBounceCount) {
+                    Trav t;
+                    traverse<INSTR>(P, rpos, rdir, rinv, laneStack(lds, P.stackDepth), t);
+                    rays++;
+                    if (INSTR) {
+                        pops += t.pops; bvc += (uint32_t)t.bvChecks; objv += t.objVisits; trii += t.triIters;
+                        tric += (uint32_t)t.triChecks;
+                        // chain the per-ray hashes the way one running hash over all rays would evolve
+                        hash = rays == 1 ? t.hash : (hash ^ t.hash) * 16777619u;
+                    }
+                    hitInfo = resolveHit(P, t, rpos, rdir);
+                }
+            }
+            float avgCandidateWeight = cr.totWeights / cr.totCandidates;
+            float correctionWeight = avgCandidateWeight / cr.chosenWeight;
+            indirectLight = indirectLight * correctionWeight;
+            v3 combined = directLight + (indirectLight / sqr(totTravelDst));
+            P.result.rgba[i] = make_float4(combined.x, combined.y, combined.z, 0.0f);
+            if (INSTR && P.records && rays) P.records[i * RECORD_DWORDS + 7] = hash;
+        }
+    }
+    if (P.stats) {
+        waveAdd(P.stats + ST_RAYS, rays);
+        waveAdd(P.stats + ST_ACTIVE, px.active ? 1u : 0u);
+        if (INSTR) {
+            waveAdd(P.stats + ST_POPS, pops); waveAdd(P.stats + ST_BVCHECKS, bvc); waveAdd(P.stats + ST_OBJVISITS, objv);
+            waveAdd(P.stats + ST_TRIITERS, trii); waveAdd(P.stats + ST_TRICHECKS, tric);
+        }
+    }
+}
+
+// AccumulateFrames (PostProcessor.compute:10-19)
+__global__ __launch_bounds__(256) void k_accumulate(const KParams P) {
+    const Pixel px = pixelOfThread(P);
+    if (!px.active) return;
+    const int64_t i = (int64_t)px.y * P.ResX + px.x;
+    float4 n = P.result.rgba[i], a = P.accumulated.rgba[i];
+    float weight = 1.0f / (float)(P.ppFrameCount + 1);
+    float4 o;
+    o.x = saturate(a.x * (1 - weight) + n.x * weight);
+    o.y = saturate(a.y * (1 - weight) + n.y * weight);
+    o.z = saturate(a.z * (1 - weight) + n.z * weight);
+    o.w = 0.0f;
+    P.accumulated.rgba[i] = o;
+}
+
+// CalcTriNormals (PreCalc.compute:11-21,39-50)
+__global__ __launch_bounds__(256) void k_calc_tri_normals(rt_triangle* tris, int64_t nTris, const rt_vertex* verts,
+                                                          int64_t nVerts, uint32_t trianglesNum) {
+    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (int64_t)trianglesNum || i >= nTris) return;
+    rt_triangle tri = tris[i];
+    auto pos = [&](int k) { return (k >= 0 && (int64_t)k < nVerts) ? V3(verts[k].pos) : V3(0, 0, 0); };
+    v3 v0 = pos(tri.vertex0Index), v1 = pos(tri.vertex1Index), v2_ = pos(tri.vertex2Index);
+    v3 n = normalize(cross(v1 - v0, v2_ - v0));
+    tris[i].localNormal = {n.x, n.y, n.z};
+}
+
+// ---------------- scene preparation kernels ----------------
+DEV uint32_t entryOf(const rt_bv* BVs, int64_t nBVs, int64_t c) {
+    if (c < 0 || c >= nBVs) return ENTRY_LEAF;  // empty leaf (rejected earlier by host validation)
+    int a = BVs[c].indexA, b = BVs[c].indexB;
+    if (a >= 0) {
+        if (b >= 0 && b <= ENTRY_INLINE_MAX_COUNT && a <= ENTRY_INLINE_MAX_START) return ENTRY_LEAF | ((uint32_t)b << 26) | (uint32_t)a;
+        return ENTRY_LEAF_INDIRECT | (uint32_t)c;
+    }
+    return (uint32_t)c;
+}
+__global__ void k_build_wide(const rt_bv* BVs, int64_t nBVs, float4* wide) {
+    int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= nBVs) return;
+    rt_bv bv = BVs[n];
+    float4 q0 = make_float4(0, 0, 0, 0), q1 = q0, q2 = q0, q3 = q0;
+    if (bv.indexA < 0) {
+        int64_t cA = -(int64_t)bv.indexA, cB = bv.indexB < 0 ? -(int64_t)bv.indexB : (int64_t)bv.indexB;
+        rt_bv A, B;
+        __builtin_memset(&A, 0, sizeof A);
+        B = A;
+        if (cA < nBVs) A = BVs[cA];
+        if (cB < nBVs) B = BVs[cB];
+        q0 = make_float4(A.min.x, A.min.y, A.min.z, A.max.x);
+        q1 = make_float4(A.max.y, A.max.z, B.min.x, B.min.y);
+        q2 = make_float4(B.min.z, B.max.x, B.max.y, B.max.z);
+        q3 = make_float4(__uint_as_float(entryOf(BVs, nBVs, cA)), __uint_as_float(entryOf(BVs, nBVs, cB)), 0, 0);
+    }
+    wide[n * 4 + 0] = q0; wide[n * 4 + 1] = q1; wide[n * 4 + 2] = q2; wide[n * 4 + 3] = q3;
+}
+__global__ void k_obj_root_entries(const rt_bv* BVs, int64_t nBVs, const rt_scene_object* objs, int64_t nObjs, uint32_t* out) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nObjs) return;
+    out[i] = entryOf(BVs, nBVs, (int64_t)(uint32_t)objs[i].bvStartIndex);
+}
+__global__ void k_bake_tris(const rt_triangle* tris, int64_t nTris, const rt_vertex* verts, int64_t nVerts, float4* out) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nTris) return;
+    rt_triangle tri = tris[i];
+    auto pos = [&](int k) { return (k >= 0 && (int64_t)k < nVerts) ? V3(verts[k].pos) : V3(0, 0, 0); };
+    v3 v0 = pos(tri.vertex0Index), v1 = pos(tri.vertex1Index), v2_ = pos(tri.vertex2Index);
+    v3 eAB = v1 - v0, eAC = v2_ - v0;
+    v3 N = cross(eAB, eAC);
+    out[i * 4 + 0] = make_float4(v0.x, v0.y, v0.z, N.x);
+    out[i * 4 + 1] = make_float4(eAB.x, eAB.y, eAB.z, N.y);
+    out[i * 4 + 2] = make_float4(eAC.x, eAC.y, eAC.z, N.z);
+    out[i * 4 + 3] = make_float4(tri.localNormal.x, tri.localNormal.y, tri.localNormal.z, 0.0f);
+}
+
+// 52-byte records <-> planes (see rt_device.h).  Field order of both record types maps onto the planes as
+// {f0..f2 -> p0.xyz}, and the rest per `kind`: 0 = reservoir, 1 = hit info.
+__global__ void k_aos_to_planes(const float* aos, Planes pl, int kind) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= pl.count) return;
+    const float* r = aos + i * 13;
+    if (kind == 0) {
+        pl.p0[i] = make_float4(r[0], r[1], r[2], r[10]);
+        pl.p1[i] = make_float4(r[3], r[4], r[5], r[11]);
+        pl.p2[i] = make_float4(r[6], r[7], r[8], r[12]);
+        pl.p3[i] = r[9];
+    } else {  // dst 0, hitPoint 1-3, uv 4-5, normal 6-8, incomingDir 9-11, materialIndex 12
+        pl.p0[i] = make_float4(r[1], r[2], r[3], r[0]);
+        pl.p1[i] = make_float4(r[6], r[7], r[8], r[12]);
+        pl.p2[i] = make_float4(r[9], r[10], r[11], r[4]);
+        pl.p3[i] = r[5];
+    }
+}
+__global__ void k_planes_to_aos(Planes pl, float* aos, int kind) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= pl.count) return;
+    float* r = aos + i * 13;
+    float4 a = pl.p0[i], b = pl.p1[i], c = pl.p2[i];
+    float d = pl.p3[i];
+    if (kind == 0) {
+        r[0] = a.x; r[1] = a.y; r[2] = a.z; r[10] = a.w;
+        r[3] = b.x; r[4] = b.y; r[5] = b.z; r[11] = b.w;
+        r[6] = c.x; r[7] = c.y; r[8] = c.z; r[12] = c.w;
+        r[9] = d;
+    } else {
+        r[1] = a.x; r[2] = a.y; r[3] = a.z; r[0] = a.w;
+        r[6] = b.x; r[7] = b.y; r[8] = b.z; r[12] = b.w;
+        r[9] = c.x; r[10] = c.y; r[11] = c.z; r[4] = c.w;
+        r[5] = d;
+    }
+}
+__global__ void k_rgba8_to_f32(const uint8_t* src, float4* dst, int64_t n) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    dst[i] = make_float4(src[i * 4] / 255.0f, src[i * 4 + 1] / 255.0f, src[i * 4 + 2] / 255.0f, src[i * 4 + 3] / 255.0f);
+}
+
+}  // namespace rtn

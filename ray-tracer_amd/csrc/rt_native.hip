@@ -1,0 +1,815 @@
+// rt_native.hip — host side of librtnative.so: the C-ABI of include/rt_native.h on top of the HIP runtime.
+//
+// Mirrors the slice of Unity's ComputeShader / ComputeBuffer / RenderTexture API the reference's host uses
+// (BVH_ReSTIR_DL/Assets/Scripts/ComputeHelper.cs, ShaderHelper.cs, Main.cs): named constants in a typeless
+// word table, named buffer/texture bindings per kernel index, keyword toggles, dispatch by kernel index.
+// Everything runs on one HIP stream per context.  There is no CPU fallback anywhere in this file.
+#include "rt_kernels.hip"
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/rt_native.h"
+
+using namespace rtn;
+
+namespace {
+
+enum ShaderKind { SH_RESTIR = 0, SH_RIS = 1, SH_PRECALC = 2, SH_POSTPROC = 3 };
+enum BufLayout { LAYOUT_AOS = 0, LAYOUT_RESERVOIR_PLANES = 1, LAYOUT_HIT_PLANES = 2 };
+
+}  // namespace
+
+struct rt_ctx_s {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string err;
+    int row0 = 0, row1 = 0;
+    int statsLevel = 0;  // 0 off, 1 rays + active pixels, 2 all counters (instrumented kernel variants)
+    uint64_t versionCounter = 1;
+    // prepared traversal data (derived from the bound scene buffers)
+    struct Prep {
+        float4* wide = nullptr; size_t wideBytes = 0;
+        float4* btri = nullptr; size_t btriBytes = 0;
+        uint32_t* objRoot = nullptr; size_t objRootBytes = 0;
+        uint64_t vBVs = 0, vTris = 0, vVerts = 0, vObjs = 0;
+        const void *pBVs = nullptr, *pTris = nullptr, *pVerts = nullptr, *pObjs = nullptr;
+        uint32_t sceneStart = 0xffffffffu;
+        uint32_t sceneRootEntry = 0;
+        int stackDepth = 0;
+        bool valid = false;
+    } prep;
+};
+
+struct rt_buffer_s {
+    rt_ctx ctx;
+    int64_t count;
+    int stride;
+    size_t bytes;
+    void* dev;
+    int layout;
+    uint64_t version;
+};
+
+struct rt_texture_s {
+    rt_ctx ctx;
+    int w, h;
+    rt_format format;
+    void* dev;     // float (R32F) or float4 (others) texels
+    size_t bytes;  // device bytes
+};
+
+struct rt_shader_s {
+    rt_ctx ctx;
+    int kind;
+    std::map<std::string, std::vector<uint32_t>> constants;
+    std::map<std::string, rt_buffer> buffers[8];
+    std::map<std::string, rt_texture> textures[8];
+    bool kwVisReuse = false, kwWeightRecalc = false, kwBrdf = false;
+    unsigned long long* statsDev = nullptr;  // 8 kernels x 8 counters, accumulated until read by rt_get_stats
+};
+
+namespace {
+
+int fail(rt_ctx ctx, int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (ctx) ctx->err = buf;
+    return code;
+}
+#define HIP_TRY(ctx, call)                                                                          \
+    do {                                                                                            \
+        hipError_t e_ = (call);                                                                     \
+        if (e_ != hipSuccess)                                                                       \
+            return fail(ctx, e_ == hipErrorOutOfMemory ? RT_ERR_OUT_OF_MEMORY : RT_ERR_NO_DEVICE,   \
+                        "%s failed: %s", #call, hipGetErrorString(e_));                             \
+    } while (0)
+
+int useDevice(rt_ctx ctx) {
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    return RT_OK;
+}
+
+Planes planesOf(rt_buffer b) {
+    Planes p;
+    char* base = (char*)b->dev;
+    p.count = b->count;
+    p.p0 = (float4*)base;
+    p.p1 = (float4*)(base + (size_t)b->count * 16);
+    p.p2 = (float4*)(base + (size_t)b->count * 32);
+    p.p3 = (float*)(base + (size_t)b->count * 48);
+    return p;
+}
+
+// Switches a 52-byte-stride buffer between the ABI's array-of-structures layout and the internal planes.
+int convertLayout(rt_buffer b, int target) {
+    if (b->layout == target) return RT_OK;
+    rt_ctx ctx = b->ctx;
+    if (b->stride != 52) return fail(ctx, RT_ERR_INVALID_ARG, "buffer stride %d cannot hold a 52-byte per-pixel record", b->stride);
+    if (b->layout != LAYOUT_AOS && target != LAYOUT_AOS) return fail(ctx, RT_ERR_INVALID_ARG, "buffer is bound as two different record types");
+    void* tmp = nullptr;
+    HIP_TRY(ctx, hipMalloc(&tmp, b->bytes));
+    int blocks = (int)((b->count + 255) / 256);
+    rt_buffer_s shadow = *b;
+    shadow.dev = tmp;
+    if (target == LAYOUT_AOS) {
+        hipLaunchKernelGGL(k_planes_to_aos, dim3(blocks), dim3(256), 0, ctx->stream, planesOf(b), (float*)tmp, b->layout == LAYOUT_RESERVOIR_PLANES ? 0 : 1);
+    } else {
+        hipLaunchKernelGGL(k_aos_to_planes, dim3(blocks), dim3(256), 0, ctx->stream, (const float*)b->dev, planesOf(&shadow), target == LAYOUT_RESERVOIR_PLANES ? 0 : 1);
+    }
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, hipFree(b->dev));
+    b->dev = tmp;
+    b->layout = target;
+    return RT_OK;
+}
+
+// ---- constant table helpers ----
+const std::vector<uint32_t>* findConst(rt_shader sh, const char* name) {
+    auto it = sh->constants.find(name);
+    return it == sh->constants.end() ? nullptr : &it->second;
+}
+uint32_t cWord(rt_shader sh, const char* name, int i = 0) {
+    const auto* v = findConst(sh, name);
+    return (v && (int)v->size() > i) ? (*v)[i] : 0u;
+}
+float cFloat(rt_shader sh, const char* name, int i = 0) {
+    uint32_t w = cWord(sh, name, i);
+    float f;
+    memcpy(&f, &w, 4);
+    return f;
+}
+// float3x3 constant from a column-major 4x4 (or a 3x3 stored the same way): out is row-major 3x3.
+void cMat3(rt_shader sh, const char* name, float out[9]) {
+    const auto* v = findConst(sh, name);
+    for (int r = 0; r < 3; r++)
+        for (int c = 0; c < 3; c++) {
+            uint32_t w = (v && v->size() >= 16) ? (*v)[c * 4 + r] : 0u;
+            memcpy(&out[r * 3 + c], &w, 4);
+        }
+}
+rt_buffer boundBuffer(rt_shader sh, int kernel, const char* name) {
+    auto it = sh->buffers[kernel].find(name);
+    return it == sh->buffers[kernel].end() ? nullptr : it->second;
+}
+rt_texture boundTexture(rt_shader sh, int kernel, const char* name) {
+    auto it = sh->textures[kernel].find(name);
+    return it == sh->textures[kernel].end() ? nullptr : it->second;
+}
+
+const int MAX_TREE_DEPTH = 96;  // deepest BVH (scene levels + mesh levels) the LDS stack is sized for
+
+// Depth (in nodes, root = 1) of the subtree at `root`; -1 on an index out of range, a cycle or excessive depth.
+// Leaves are checked against `nLeafTargets` (triangles or scene objects).
+int subtreeDepth(const std::vector<rt_bv>& bvs, uint32_t root, int64_t nLeafTargets, std::vector<uint8_t>& seen,
+                 std::string& why) {
+    struct Item { uint32_t node; int depth; };
+    std::vector<Item> st;
+    st.push_back({root, 1});
+    int maxDepth = 0;
+    while (!st.empty()) {
+        Item it = st.back();
+        st.pop_back();
+        if (it.node >= bvs.size()) { why = "BVH child index out of range"; return -1; }
+        if (it.depth > MAX_TREE_DEPTH) { why = "BVH deeper than the supported maximum"; return -1; }
+        if (seen[it.node] == 2) { why = "BVH node reachable twice (cycle or shared subtree)"; return -1; }
+        seen[it.node] = 2;
+        if (it.depth > maxDepth) maxDepth = it.depth;
+        const rt_bv& bv = bvs[it.node];
+        if (bv.indexA >= 0) {
+            int64_t start = bv.indexA, count = bv.indexB < 0 ? -(int64_t)bv.indexB : bv.indexB;
+            if (start + count > nLeafTargets) { why = "BVH leaf range exceeds its component buffer"; return -1; }
+        } else {
+            int64_t a = -(int64_t)bv.indexA, b = bv.indexB < 0 ? -(int64_t)bv.indexB : bv.indexB;
+            st.push_back({(uint32_t)a, it.depth + 1});
+            st.push_back({(uint32_t)b, it.depth + 1});
+        }
+    }
+    return maxDepth;
+}
+
+// Validates the scene buffers the traversal kernels index without bounds checks and (re)builds the derived
+// device arrays: wide BVH nodes, baked triangles, per-object root entries.  Cached on the buffers' versions.
+int prepareScene(rt_shader sh, int kernel, KParams& P) {
+    rt_ctx ctx = sh->ctx;
+    rt_buffer bBVs = boundBuffer(sh, kernel, "BVs"), bTris = boundBuffer(sh, kernel, "Triangles"),
+              bVerts = boundBuffer(sh, kernel, "Vertices"), bObjs = boundBuffer(sh, kernel, "SceneObjects"),
+              bMats = boundBuffer(sh, kernel, "Materials");
+    if (!bBVs || !bTris || !bVerts || !bObjs || !bMats)
+        return fail(ctx, RT_ERR_UNBOUND, "kernel %d needs BVs, Triangles, Vertices, SceneObjects and Materials bound", kernel);
+    if (bBVs->stride != 32 || bTris->stride != 28 || bVerts->stride != 20 || bObjs->stride != 168 || bMats->stride != 108)
+        return fail(ctx, RT_ERR_INVALID_ARG, "scene buffer strides must be BVs 32, Triangles 28, Vertices 20, SceneObjects 168, Materials 108");
+    const uint32_t sceneStart = cWord(sh, "SceneBVHStartIndex");
+    auto& pr = ctx->prep;
+    const bool fresh = pr.valid && pr.vBVs == bBVs->version && pr.vTris == bTris->version && pr.vVerts == bVerts->version &&
+                       pr.vObjs == bObjs->version && pr.pBVs == bBVs->dev && pr.pTris == bTris->dev && pr.pVerts == bVerts->dev &&
+                       pr.pObjs == bObjs->dev && pr.sceneStart == sceneStart;
+    if (!fresh) {
+        pr.valid = false;
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        std::vector<rt_bv> bvs((size_t)bBVs->count);
+        std::vector<rt_scene_object> objs((size_t)bObjs->count);
+        std::vector<rt_triangle> tris((size_t)bTris->count);
+        HIP_TRY(ctx, hipMemcpy(bvs.data(), bBVs->dev, bvs.size() * sizeof(rt_bv), hipMemcpyDeviceToHost));
+        HIP_TRY(ctx, hipMemcpy(objs.data(), bObjs->dev, objs.size() * sizeof(rt_scene_object), hipMemcpyDeviceToHost));
+        HIP_TRY(ctx, hipMemcpy(tris.data(), bTris->dev, tris.size() * sizeof(rt_triangle), hipMemcpyDeviceToHost));
+        if (bvs.size() >= (size_t)ENTRY_INDEX_MASK) return fail(ctx, RT_ERR_BAD_SCENE, "too many BVH nodes");
+        for (const auto& t : tris)
+            if (t.vertex0Index < 0 || t.vertex1Index < 0 || t.vertex2Index < 0 || t.vertex0Index >= bVerts->count ||
+                t.vertex1Index >= bVerts->count || t.vertex2Index >= bVerts->count)
+                return fail(ctx, RT_ERR_BAD_SCENE, "a triangle's vertex index is outside the Vertices buffer");
+        std::vector<uint8_t> seen(bvs.size(), 0);
+        std::string why;
+        int sceneDepth = subtreeDepth(bvs, sceneStart, bObjs->count, seen, why);
+        if (sceneDepth < 0) return fail(ctx, RT_ERR_BAD_SCENE, "scene BVH (SceneBVHStartIndex %u): %s", sceneStart, why.c_str());
+        std::map<int, int> meshDepth;  // bvStartIndex -> depth
+        int maxMeshDepth = 0;
+        for (const auto& o : objs) {
+            if (meshDepth.count(o.bvStartIndex)) continue;
+            if (o.bvStartIndex < 0) return fail(ctx, RT_ERR_BAD_SCENE, "scene object with negative bvStartIndex");
+            int d = subtreeDepth(bvs, (uint32_t)o.bvStartIndex, bTris->count, seen, why);
+            if (d < 0) return fail(ctx, RT_ERR_BAD_SCENE, "mesh BVH at %d: %s", o.bvStartIndex, why.c_str());
+            meshDepth[o.bvStartIndex] = d;
+            if (d > maxMeshDepth) maxMeshDepth = d;
+        }
+        pr.stackDepth = sceneDepth + maxMeshDepth + 2;
+
+        auto ensure = [&](void** p, size_t* have, size_t need) -> int {
+            if (*have >= need && *p) return RT_OK;
+            if (*p) { hipError_t e = hipFree(*p); (void)e; *p = nullptr; *have = 0; }
+            HIP_TRY(ctx, hipMalloc(p, need));
+            *have = need;
+            return RT_OK;
+        };
+        int rc;
+        if ((rc = ensure((void**)&pr.wide, &pr.wideBytes, (size_t)bBVs->count * 64))) return rc;
+        if ((rc = ensure((void**)&pr.btri, &pr.btriBytes, (size_t)bTris->count * 64))) return rc;
+        if ((rc = ensure((void**)&pr.objRoot, &pr.objRootBytes, (size_t)bObjs->count * 4))) return rc;
+        hipLaunchKernelGGL(k_build_wide, dim3((unsigned)((bBVs->count + 255) / 256)), dim3(256), 0, ctx->stream,
+                           (const rt_bv*)bBVs->dev, bBVs->count, pr.wide);
+        hipLaunchKernelGGL(k_bake_tris, dim3((unsigned)((bTris->count + 255) / 256)), dim3(256), 0, ctx->stream,
+                           (const rt_triangle*)bTris->dev, bTris->count, (const rt_vertex*)bVerts->dev, bVerts->count, pr.btri);
+        hipLaunchKernelGGL(k_obj_root_entries, dim3((unsigned)((bObjs->count + 255) / 256)), dim3(256), 0, ctx->stream,
+                           (const rt_bv*)bBVs->dev, bBVs->count, (const rt_scene_object*)bObjs->dev, bObjs->count, pr.objRoot);
+        HIP_TRY(ctx, hipGetLastError());
+        // stack entry of the scene root, same rule as the device-side entryOf()
+        {
+            const rt_bv& r = bvs[sceneStart];
+            if (r.indexA >= 0) {
+                if (r.indexB >= 0 && r.indexB <= ENTRY_INLINE_MAX_COUNT && r.indexA <= ENTRY_INLINE_MAX_START)
+                    pr.sceneRootEntry = ENTRY_LEAF | ((uint32_t)r.indexB << 26) | (uint32_t)r.indexA;
+                else pr.sceneRootEntry = ENTRY_LEAF_INDIRECT | sceneStart;
+            } else pr.sceneRootEntry = sceneStart;
+        }
+        pr.vBVs = bBVs->version; pr.vTris = bTris->version; pr.vVerts = bVerts->version; pr.vObjs = bObjs->version;
+        pr.pBVs = bBVs->dev; pr.pTris = bTris->dev; pr.pVerts = bVerts->dev; pr.pObjs = bObjs->dev;
+        pr.sceneStart = sceneStart;
+        pr.valid = true;
+    }
+    P.wide = pr.wide; P.btri = pr.btri; P.objRootEntry = pr.objRoot;
+    P.BVs = (const rt_bv*)bBVs->dev; P.nBVs = bBVs->count;
+    P.objs = (const rt_scene_object*)bObjs->dev; P.nObjs = bObjs->count;
+    P.tris = (const rt_triangle*)bTris->dev; P.nTris = bTris->count;
+    P.verts = (const rt_vertex*)bVerts->dev; P.nVerts = bVerts->count;
+    P.mats = (const rt_material*)bMats->dev; P.nMats = bMats->count;
+    P.sceneRootEntry = pr.sceneRootEntry;
+    P.stackDepth = pr.stackDepth;
+    return RT_OK;
+}
+
+int needPlanes(rt_shader sh, int kernel, const char* name, int layout, Planes& out) {
+    rt_buffer b = boundBuffer(sh, kernel, name);
+    if (!b) return fail(sh->ctx, RT_ERR_UNBOUND, "kernel %d: buffer '%s' is not bound", kernel, name);
+    int rc = convertLayout(b, layout);
+    if (rc) return rc;
+    out = planesOf(b);
+    return RT_OK;
+}
+int needTex(rt_shader sh, int kernel, const char* name, bool r32, int resX, int resY, Tex& out) {
+    rt_texture t = boundTexture(sh, kernel, name);
+    if (!t) return fail(sh->ctx, RT_ERR_UNBOUND, "kernel %d: texture '%s' is not bound", kernel, name);
+    if ((t->format == RT_FORMAT_R32F) != r32) return fail(sh->ctx, RT_ERR_INVALID_ARG, "texture '%s' has the wrong format", name);
+    if (t->w != resX || t->h != resY) return fail(sh->ctx, RT_ERR_INVALID_ARG, "texture '%s' is %dx%d but Resolution is %dx%d", name, t->w, t->h, resX, resY);
+    out.w = t->w; out.h = t->h;
+    out.rgba = r32 ? nullptr : (float4*)t->dev;
+    out.r = r32 ? (float*)t->dev : nullptr;
+    return RT_OK;
+}
+void optionalTex(rt_shader sh, int kernel, const char* name, Tex& out) {
+    rt_texture t = boundTexture(sh, kernel, name);
+    out.rgba = nullptr; out.r = nullptr; out.w = out.h = 0;
+    if (t && t->format != RT_FORMAT_R32F) { out.rgba = (float4*)t->dev; out.w = t->w; out.h = t->h; }
+}
+
+void fillConstants(rt_shader sh, KParams& P) {
+    P.MaxBVHDepth = cWord(sh, "MaxBVHDepth");
+    P.ScatterProbability = cFloat(sh, "ScatterProbability");
+    P.MaxBounceCount = cWord(sh, "MaxBounceCount");
+    P.ResX = (int32_t)cWord(sh, "Resolution", 0);
+    P.ResY = (int32_t)cWord(sh, "Resolution", 1);
+    P.ViewSpaceDimsX = cFloat(sh, "ViewSpaceDims", 0);
+    P.ViewSpaceDimsY = cFloat(sh, "ViewSpaceDims", 1);
+    P.DefocusStrength = cFloat(sh, "DefocusStrength");
+    P.FocalPlaneFactor = cFloat(sh, "FocalPlaneFactor");
+    for (int i = 0; i < 3; i++) { P.camPos[i] = cFloat(sh, "WorldSpaceCameraPos", i); P.lastCamPos[i] = cFloat(sh, "LastWorldSpaceCameraPos", i); }
+    cMat3(sh, "CameraTransform", P.camT);
+    cMat3(sh, "LastCameraTransformInverse", P.lastCamTInv);
+    P.FrameRand = cWord(sh, "FrameRand");
+    P.FrameCount = cWord(sh, "FrameCount");
+    P.DebugMaxX = (int32_t)cWord(sh, "DebugDataMaxValues", 0);
+    P.DebugMaxY = (int32_t)cWord(sh, "DebugDataMaxValues", 1);
+    P.SceneObjectReservoirTestsNum = cWord(sh, "SceneObjectReservoirTestsNum");
+    P.TriReservoirTestsNum = cWord(sh, "TriReservoirTestsNum");
+    P.ReuseBufferCycle = (int32_t)cWord(sh, "ReuseBufferCycle");
+    P.MaxOffset = (int32_t)cWord(sh, "MaxOffset");
+    P.TemporalCandidatesNum = cWord(sh, "TemporalCandidatesNum");
+    P.SpatialHitPointDiffThreshold = cFloat(sh, "SpatialHitPointDiffThreshold");
+    P.SpatialNormalsAngleThreshold = cFloat(sh, "SpatialNormalsAngleThreshold");
+    P.SpatialBRDFThreshold = cFloat(sh, "SpatialBRDFThreshold");
+    P.TemporalReuseWeight = cFloat(sh, "TemporalReuseWeight");
+    P.PixelMovementThreshold = cFloat(sh, "PixelMovementThreshold");
+    P.TemporalPrecisionThreshold = cFloat(sh, "TemporalPrecisionThreshold");
+    P.EmittingObjectsNum = cWord(sh, "EmittingObjectsNum");
+    P.atlasDimsX = cFloat(sh, "TextureAtlasDims", 0);
+    P.atlasDimsY = cFloat(sh, "TextureAtlasDims", 1);
+    P.envDimsX = cFloat(sh, "EnvironmentMapTexDims", 0);
+    P.envDimsY = cFloat(sh, "EnvironmentMapTexDims", 1);
+    P.kwVisReuse = sh->kwVisReuse; P.kwWeightRecalc = sh->kwWeightRecalc; P.kwBrdf = sh->kwBrdf;
+    P.ppFrameCount = (int32_t)cWord(sh, "FrameCount");
+}
+
+// Launch geometry of the per-pixel kernels: 256-thread workgroups, each a 2x2 group of 8x8 tiles, covering the
+// context's row band (whole image by default).  The caller's group counts only have to cover the image.
+int pixelGrid(rt_ctx ctx, KParams& P, int gx, int gy, unsigned* blocks) {
+    if (P.ResX <= 0 || P.ResY <= 0) return fail(ctx, RT_ERR_UNBOUND, "constant 'Resolution' is not set");
+    if ((int64_t)gx * 8 < P.ResX || (int64_t)gy * 8 < P.ResY)
+        return fail(ctx, RT_ERR_INVALID_ARG, "dispatch of %dx%d groups does not cover Resolution %dx%d", gx, gy, P.ResX, P.ResY);
+    P.row0 = 0; P.row1 = P.ResY;
+    if (ctx->row1 > 0) { P.row0 = ctx->row0 < 0 ? 0 : ctx->row0; P.row1 = ctx->row1 < P.ResY ? ctx->row1 : P.ResY; }
+    if (P.row1 <= P.row0) { *blocks = 0; return RT_OK; }
+    int bandY0 = P.row0 & ~7;
+    unsigned bx = (unsigned)(P.ResX + 15) / 16, by = (unsigned)(P.row1 - bandY0 + 15) / 16;
+    *blocks = bx * by;
+    return RT_OK;
+}
+
+void beginStats(rt_shader sh, int kernel, KParams& P) {
+    P.stats = (sh->ctx->statsLevel > 0 && sh->statsDev) ? sh->statsDev + kernel * 8 : nullptr;
+}
+
+int dispatchReSTIR(rt_shader sh, int kernel, int gx, int gy) {
+    rt_ctx ctx = sh->ctx;
+    KParams P;
+    memset(&P, 0, sizeof P);
+    fillConstants(sh, P);
+    unsigned blocks = 0;
+    int rc = pixelGrid(ctx, P, gx, gy, &blocks);
+    if (rc) return rc;
+    const int X = P.ResX, Y = P.ResY;
+    const int64_t npx = (int64_t)X * Y;
+    auto checkCount = [&](const Planes& pl, const char* name) -> int {
+        if (pl.count < npx) return fail(ctx, RT_ERR_INVALID_ARG, "buffer '%s' holds %lld records, Resolution needs %lld", name, (long long)pl.count, (long long)npx);
+        return RT_OK;
+    };
+    rt_buffer rec = boundBuffer(sh, kernel, "TraceRecords");
+    bool instr = false;
+    if (rec) {
+        if (rec->stride != RECORD_DWORDS * 4 || rec->count < npx) return fail(ctx, RT_ERR_INVALID_ARG, "TraceRecords must have stride 32 and one record per pixel");
+        P.records = (uint32_t*)rec->dev;
+        instr = true;
+    }
+    if (ctx->statsLevel >= 2) instr = true;
+    beginStats(sh, kernel, P);
+    switch (kernel) {
+        case 0: {  // InitialTrace
+            if ((rc = prepareScene(sh, kernel, P))) return rc;
+            rt_buffer lights = boundBuffer(sh, kernel, "LightObjects");
+            if (!lights) return fail(ctx, RT_ERR_UNBOUND, "kernel 0: buffer 'LightObjects' is not bound");
+            if (lights->stride != 80) return fail(ctx, RT_ERR_INVALID_ARG, "LightObjects stride must be 80");
+            P.lights = (const rt_light_object*)lights->dev; P.nLights = lights->count;
+            if ((rc = needPlanes(sh, kernel, "HitInfos", LAYOUT_HIT_PLANES, P.hit)) || (rc = checkCount(P.hit, "HitInfos"))) return rc;
+            if ((rc = needPlanes(sh, kernel, "Candidates", LAYOUT_RESERVOIR_PLANES, P.cand)) || (rc = checkCount(P.cand, "Candidates"))) return rc;
+            if ((rc = needTex(sh, kernel, "DebugOverlay", false, X, Y, P.debugOverlay))) return rc;
+            if ((rc = needTex(sh, kernel, "DepthBuffer", true, X, Y, P.depth))) return rc;
+            if ((rc = needTex(sh, kernel, "NormalsBuffer", false, X, Y, P.normals))) return rc;
+            if ((rc = needTex(sh, kernel, "RayHitPointsA", false, X, Y, P.hitA))) return rc;
+            if ((rc = needTex(sh, kernel, "RayHitPointsB", false, X, Y, P.hitB))) return rc;
+            optionalTex(sh, kernel, "TextureAtlas", P.atlas);
+            if (!blocks) break;
+            size_t ldsBytes = (size_t)WAVES_PER_BLOCK * P.stackDepth * 64 * 4;
+            if (instr) {
+                hipLaunchKernelGGL(k_primary<true>, dim3(blocks), dim3(256), ldsBytes, ctx->stream, P);
+                hipLaunchKernelGGL(k_candidates<true>, dim3(blocks), dim3(256), ldsBytes, ctx->stream, P);
+            } else {
+                hipLaunchKernelGGL(k_primary<false>, dim3(blocks), dim3(256), ldsBytes, ctx->stream, P);
+                hipLaunchKernelGGL(k_candidates<false>, dim3(blocks), dim3(256), ldsBytes, ctx->stream, P);
+            }
+            break;
+        }
+        case 1: {  // SpatialReusePass
+            if ((rc = needPlanes(sh, kernel, "Candidates", LAYOUT_RESERVOIR_PLANES, P.cand)) || (rc = checkCount(P.cand, "Candidates"))) return rc;
+            if ((rc = needPlanes(sh, kernel, "CandidatesB", LAYOUT_RESERVOIR_PLANES, P.candB)) || (rc = checkCount(P.candB, "CandidatesB"))) return rc;
+            if ((rc = needTex(sh, kernel, "DepthBuffer", true, X, Y, P.depth))) return rc;
+            if (blocks) hipLaunchKernelGGL(k_spatial, dim3(blocks), dim3(256), 0, ctx->stream, P);
+            break;
+        }
+        case 2: {  // TransferToOriginal
+            if ((rc = needPlanes(sh, kernel, "Candidates", LAYOUT_RESERVOIR_PLANES, P.cand)) || (rc = checkCount(P.cand, "Candidates"))) return rc;
+            if ((rc = needPlanes(sh, kernel, "CandidatesB", LAYOUT_RESERVOIR_PLANES, P.candB)) || (rc = checkCount(P.candB, "CandidatesB"))) return rc;
+            if ((rc = needTex(sh, kernel, "DepthBuffer", true, X, Y, P.depth))) return rc;
+            if (blocks) hipLaunchKernelGGL(k_transfer, dim3(blocks), dim3(256), 0, ctx->stream, P);
+            break;
+        }
+        case 3: {  // TemporalReuse
+            if ((rc = needPlanes(sh, kernel, "Candidates", LAYOUT_RESERVOIR_PLANES, P.cand)) || (rc = checkCount(P.cand, "Candidates"))) return rc;
+            if ((rc = needPlanes(sh, kernel, "TemporalFrameBuffer", LAYOUT_RESERVOIR_PLANES, P.temporal)) || (rc = checkCount(P.temporal, "TemporalFrameBuffer"))) return rc;
+            if ((rc = needTex(sh, kernel, "DepthBuffer", true, X, Y, P.depth))) return rc;
+            if ((rc = needTex(sh, kernel, "RayHitPointsA", false, X, Y, P.hitA))) return rc;
+            if ((rc = needTex(sh, kernel, "RayHitPointsB", false, X, Y, P.hitB))) return rc;
+            if (blocks) hipLaunchKernelGGL(k_temporal, dim3(blocks), dim3(256), 0, ctx->stream, P);
+            break;
+        }
+        case 4: {  // TraceRays
+            if ((rc = prepareScene(sh, kernel, P))) return rc;
+            if ((rc = needPlanes(sh, kernel, "HitInfos", LAYOUT_HIT_PLANES, P.hit)) || (rc = checkCount(P.hit, "HitInfos"))) return rc;
+            if ((rc = needPlanes(sh, kernel, "Candidates", LAYOUT_RESERVOIR_PLANES, P.cand)) || (rc = checkCount(P.cand, "Candidates"))) return rc;
+            if ((rc = needPlanes(sh, kernel, "TemporalFrameBuffer", LAYOUT_RESERVOIR_PLANES, P.temporal)) || (rc = checkCount(P.temporal, "TemporalFrameBuffer"))) return rc;
+            if ((rc = needTex(sh, kernel, "Result", false, X, Y, P.result))) return rc;
+            optionalTex(sh, kernel, "TextureAtlas", P.atlas);
+            optionalTex(sh, kernel, "EnvironmentMap", P.env);
+            if (!blocks) break;
+            size_t ldsBytes = (size_t)WAVES_PER_BLOCK * P.stackDepth * 64 * 4;
+            if (instr) hipLaunchKernelGGL(k_trace_rays<true>, dim3(blocks), dim3(256), ldsBytes, ctx->stream, P);
+            else hipLaunchKernelGGL(k_trace_rays<false>, dim3(blocks), dim3(256), ldsBytes, ctx->stream, P);
+            break;
+        }
+        default: return fail(ctx, RT_ERR_INVALID_ARG, "ReSTIR_BVH_RayTracer has no kernel %d", kernel);
+    }
+    HIP_TRY(ctx, hipGetLastError());
+    return RT_OK;
+}
+
+int dispatchPreCalc(rt_shader sh, int kernel, int gx) {
+    rt_ctx ctx = sh->ctx;
+    if (kernel != 0) return fail(ctx, RT_ERR_INVALID_ARG, "PreCalc has no kernel %d", kernel);
+    rt_buffer bTris = boundBuffer(sh, 0, "Triangles"), bVerts = boundBuffer(sh, 0, "Vertices");
+    if (!bTris || !bVerts) return fail(ctx, RT_ERR_UNBOUND, "CalcTriNormals needs Triangles and Vertices bound");
+    if (bTris->stride != 28 || bVerts->stride != 20) return fail(ctx, RT_ERR_INVALID_ARG, "CalcTriNormals: Triangles stride must be 28 and Vertices 20");
+    uint32_t trianglesNum = cWord(sh, "TrianglesNum");
+    if (gx <= 0) return RT_OK;
+    // threads beyond the dispatched groups do not run, exactly as with the reference's dispatch
+    uint64_t covered = (uint64_t)gx * 256;
+    uint32_t n = trianglesNum < covered ? trianglesNum : (uint32_t)covered;
+    hipLaunchKernelGGL(k_calc_tri_normals, dim3((unsigned)gx), dim3(256), 0, ctx->stream, (rt_triangle*)bTris->dev, bTris->count,
+                       (const rt_vertex*)bVerts->dev, bVerts->count, n);
+    HIP_TRY(ctx, hipGetLastError());
+    bTris->version = ctx->versionCounter++;
+    return RT_OK;
+}
+
+int dispatchPostProc(rt_shader sh, int kernel, int gx, int gy) {
+    rt_ctx ctx = sh->ctx;
+    if (kernel != 0) return fail(ctx, RT_ERR_INVALID_ARG, "PostProcessor has no kernel %d", kernel);
+    KParams P;
+    memset(&P, 0, sizeof P);
+    rt_texture res = boundTexture(sh, 0, "Result"), acc = boundTexture(sh, 0, "AccumulatedResult");
+    if (!res || !acc) return fail(ctx, RT_ERR_UNBOUND, "AccumulateFrames needs Result and AccumulatedResult bound");
+    if (res->format == RT_FORMAT_R32F || acc->format == RT_FORMAT_R32F || res->w != acc->w || res->h != acc->h)
+        return fail(ctx, RT_ERR_INVALID_ARG, "AccumulateFrames: Result and AccumulatedResult must be RGBA textures of equal size");
+    // The kernel has no bounds check (PostProcessor.compute:11-18); threads outside the textures read 0 and
+    // their writes are dropped, so the covered region is the intersection of the dispatch and the texture.
+    P.ResX = res->w; P.ResY = res->h;
+    P.ppFrameCount = (int32_t)cWord(sh, "FrameCount");
+    P.result.rgba = (float4*)res->dev; P.accumulated.rgba = (float4*)acc->dev;
+    unsigned blocks = 0;
+    int rc = pixelGrid(ctx, P, gx, gy, &blocks);
+    if (rc) return rc;
+    if (blocks) hipLaunchKernelGGL(k_accumulate, dim3(blocks), dim3(256), 0, ctx->stream, P);
+    HIP_TRY(ctx, hipGetLastError());
+    return RT_OK;
+}
+
+}  // namespace
+
+// =============================================================== C-ABI ===============================================================
+extern "C" {
+
+int rt_create(int device_id, rt_ctx* out) {
+    if (!out) return RT_ERR_INVALID_ARG;
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0 || device_id < 0 || device_id >= n) return RT_ERR_NO_DEVICE;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device_id) != hipSuccess) return RT_ERR_NO_DEVICE;
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) return RT_ERR_NO_DEVICE;  // the only code object in this library
+    rt_ctx ctx = new rt_ctx_s;
+    ctx->device = device_id;
+    if (hipSetDevice(device_id) != hipSuccess || hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
+        delete ctx;
+        return RT_ERR_NO_DEVICE;
+    }
+    *out = ctx;
+    return RT_OK;
+}
+
+void rt_destroy(rt_ctx ctx) {
+    if (!ctx) return;
+    hipError_t e = hipSetDevice(ctx->device);
+    e = hipStreamSynchronize(ctx->stream);
+    if (ctx->prep.wide) e = hipFree(ctx->prep.wide);
+    if (ctx->prep.btri) e = hipFree(ctx->prep.btri);
+    if (ctx->prep.objRoot) e = hipFree(ctx->prep.objRoot);
+    e = hipStreamDestroy(ctx->stream);
+    (void)e;
+    delete ctx;
+}
+
+int rt_sync(rt_ctx ctx) {
+    if (!ctx) return RT_ERR_INVALID_ARG;
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return RT_OK;
+}
+const char* rt_last_error(rt_ctx ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+void* rt_stream(rt_ctx ctx) { return ctx ? (void*)ctx->stream : nullptr; }
+
+int rt_set_row_band(rt_ctx ctx, int row0, int row1) {
+    if (!ctx) return RT_ERR_INVALID_ARG;
+    if (row1 > 0 && (row0 < 0 || row0 > row1)) return fail(ctx, RT_ERR_INVALID_ARG, "row band [%d,%d) is not valid", row0, row1);
+    ctx->row0 = row0; ctx->row1 = row1;
+    return RT_OK;
+}
+
+int rt_shader_open(rt_ctx ctx, const char* name, rt_shader* out) {
+    if (!ctx || !name || !out) return RT_ERR_INVALID_ARG;
+    int kind;
+    if (!strcmp(name, "ReSTIR_BVH_RayTracer")) kind = SH_RESTIR;
+    else if (!strcmp(name, "RIS_BVH_RayTracer")) kind = SH_RIS;
+    else if (!strcmp(name, "PreCalc")) kind = SH_PRECALC;
+    else if (!strcmp(name, "PostProcessor")) kind = SH_POSTPROC;
+    else return fail(ctx, RT_ERR_INVALID_ARG, "unknown shader '%s'", name);
+    if (kind == SH_RIS) return fail(ctx, RT_ERR_INVALID_ARG, "shader 'RIS_BVH_RayTracer' is not built into this library yet");
+    int rc = useDevice(ctx);
+    if (rc) return rc;
+    rt_shader sh = new rt_shader_s;
+    sh->ctx = ctx;
+    sh->kind = kind;
+    hipError_t e = hipMalloc((void**)&sh->statsDev, 64 * sizeof(unsigned long long));
+    if (e == hipSuccess) e = hipMemsetAsync(sh->statsDev, 0, 64 * sizeof(unsigned long long), ctx->stream);
+    if (e != hipSuccess) {
+        delete sh;
+        return fail(ctx, RT_ERR_NO_DEVICE, "shader open failed: %s", hipGetErrorString(e));
+    }
+    *out = sh;
+    return RT_OK;
+}
+void rt_shader_close(rt_shader sh) {
+    if (!sh) return;
+    hipError_t e = hipSetDevice(sh->ctx->device);
+    e = hipStreamSynchronize(sh->ctx->stream);
+    if (sh->statsDev) e = hipFree(sh->statsDev);
+    (void)e;
+    delete sh;
+}
+
+int rt_find_kernel(rt_shader sh, const char* name) {
+    if (!sh || !name) return RT_ERR_INVALID_ARG;
+    static const char* restir[] = {"InitialTrace", "SpatialReusePass", "TransferToOriginal", "TemporalReuse", "TraceRays"};
+    switch (sh->kind) {
+        case SH_RESTIR:
+            for (int i = 0; i < 5; i++) if (!strcmp(name, restir[i])) return i;
+            break;
+        case SH_PRECALC: if (!strcmp(name, "CalcTriNormals")) return 0; break;
+        case SH_POSTPROC: if (!strcmp(name, "AccumulateFrames")) return 0; break;
+    }
+    return fail(sh->ctx, RT_ERR_INVALID_ARG, "kernel '%s' not found", name);
+}
+
+int rt_dispatch(rt_shader sh, int kernel, int gx, int gy, int gz) {
+    if (!sh) return RT_ERR_INVALID_ARG;
+    rt_ctx ctx = sh->ctx;
+    if (kernel < 0 || kernel >= 8) return fail(ctx, RT_ERR_INVALID_ARG, "kernel index %d out of range", kernel);
+    if (gx < 0 || gy < 0 || gz < 0) return fail(ctx, RT_ERR_INVALID_ARG, "negative thread-group count");
+    int rc = useDevice(ctx);
+    if (rc) return rc;
+    if (gx == 0 || gy == 0 || gz == 0) return RT_OK;
+    switch (sh->kind) {
+        case SH_RESTIR: return dispatchReSTIR(sh, kernel, gx, gy);
+        case SH_PRECALC: return dispatchPreCalc(sh, kernel, gx);
+        case SH_POSTPROC: return dispatchPostProc(sh, kernel, gx, gy);
+    }
+    return fail(ctx, RT_ERR_INVALID_ARG, "shader kind %d cannot be dispatched", sh->kind);
+}
+
+int rt_enable_keyword(rt_shader sh, const char* kw) {
+    if (!sh || !kw) return RT_ERR_INVALID_ARG;
+    if (!strcmp(kw, "VIS_REUSE")) sh->kwVisReuse = true;
+    else if (!strcmp(kw, "WEIGHT_RECALC")) sh->kwWeightRecalc = true;
+    else if (!strcmp(kw, "BRDF")) sh->kwBrdf = true;
+    return RT_OK;
+}
+int rt_disable_keyword(rt_shader sh, const char* kw) {
+    if (!sh || !kw) return RT_ERR_INVALID_ARG;
+    if (!strcmp(kw, "VIS_REUSE")) sh->kwVisReuse = false;
+    else if (!strcmp(kw, "WEIGHT_RECALC")) sh->kwWeightRecalc = false;
+    else if (!strcmp(kw, "BRDF")) sh->kwBrdf = false;
+    return RT_OK;
+}
+
+static int setWords(rt_shader sh, const char* name, const void* src, int nwords) {
+    if (!sh || !name || (!src && nwords)) return RT_ERR_INVALID_ARG;
+    if (nwords < 0 || nwords > 64) return fail(sh->ctx, RT_ERR_INVALID_ARG, "constant '%s': %d words", name, nwords);
+    std::vector<uint32_t>& v = sh->constants[name];
+    v.resize((size_t)nwords);
+    if (nwords) memcpy(v.data(), src, (size_t)nwords * 4);
+    return RT_OK;
+}
+int rt_set_int(rt_shader sh, const char* name, int value) { return setWords(sh, name, &value, 1); }
+int rt_set_float(rt_shader sh, const char* name, float value) { return setWords(sh, name, &value, 1); }
+int rt_set_bool(rt_shader sh, const char* name, int value) { int v = value ? 1 : 0; return setWords(sh, name, &v, 1); }
+int rt_set_ints(rt_shader sh, const char* name, const int* values, int count) { return setWords(sh, name, values, count); }
+int rt_set_vector(rt_shader sh, const char* name, const float values[4]) { return setWords(sh, name, values, 4); }
+int rt_set_matrix(rt_shader sh, const char* name, const float values[16]) { return setWords(sh, name, values, 16); }
+
+int rt_set_buffer(rt_shader sh, int kernel, const char* name, rt_buffer buf) {
+    if (!sh || !name) return RT_ERR_INVALID_ARG;
+    if (kernel < 0 || kernel >= 8) return fail(sh->ctx, RT_ERR_INVALID_ARG, "kernel index %d out of range", kernel);
+    if (buf && buf->ctx != sh->ctx) return fail(sh->ctx, RT_ERR_INVALID_ARG, "buffer belongs to another context");
+    if (buf) sh->buffers[kernel][name] = buf; else sh->buffers[kernel].erase(name);
+    return RT_OK;
+}
+int rt_set_texture(rt_shader sh, int kernel, const char* name, rt_texture tex) {
+    if (!sh || !name) return RT_ERR_INVALID_ARG;
+    if (kernel < 0 || kernel >= 8) return fail(sh->ctx, RT_ERR_INVALID_ARG, "kernel index %d out of range", kernel);
+    if (tex && tex->ctx != sh->ctx) return fail(sh->ctx, RT_ERR_INVALID_ARG, "texture belongs to another context");
+    if (tex) sh->textures[kernel][name] = tex; else sh->textures[kernel].erase(name);
+    return RT_OK;
+}
+
+int rt_buffer_create(rt_ctx ctx, int64_t count, int stride, rt_buffer* out) {
+    if (!ctx || !out) return RT_ERR_INVALID_ARG;
+    *out = nullptr;
+    if (count < 1 || stride < 4 || stride % 4 != 0) return fail(ctx, RT_ERR_INVALID_ARG, "buffer count %lld / stride %d invalid", (long long)count, stride);
+    int rc = useDevice(ctx);
+    if (rc) return rc;
+    rt_buffer b = new rt_buffer_s;
+    b->ctx = ctx; b->count = count; b->stride = stride; b->bytes = (size_t)count * stride; b->layout = LAYOUT_AOS;
+    b->version = ctx->versionCounter++;
+    b->dev = nullptr;
+    hipError_t e = hipMalloc(&b->dev, b->bytes);
+    if (e == hipSuccess) e = hipMemsetAsync(b->dev, 0, b->bytes, ctx->stream);
+    if (e != hipSuccess) {
+        if (b->dev) { hipError_t e2 = hipFree(b->dev); (void)e2; }
+        delete b;
+        return fail(ctx, e == hipErrorOutOfMemory ? RT_ERR_OUT_OF_MEMORY : RT_ERR_NO_DEVICE, "buffer allocation of %zu bytes failed: %s", (size_t)count * stride, hipGetErrorString(e));
+    }
+    *out = b;
+    return RT_OK;
+}
+
+int rt_buffer_set_data(rt_buffer b, const void* src, size_t bytes) {
+    if (!b || (!src && bytes)) return RT_ERR_INVALID_ARG;
+    rt_ctx ctx = b->ctx;
+    if (bytes > b->bytes) return fail(ctx, RT_ERR_INVALID_ARG, "set_data of %zu bytes into a %zu-byte buffer", bytes, b->bytes);
+    int rc = useDevice(ctx);
+    if (rc) return rc;
+    if ((rc = convertLayout(b, LAYOUT_AOS))) return rc;
+    // synchronous copy: the caller may reuse `src` as soon as this returns
+    HIP_TRY(ctx, hipMemcpyAsync(b->dev, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    b->version = ctx->versionCounter++;
+    return RT_OK;
+}
+
+int rt_buffer_get_data(rt_buffer b, void* dst, size_t bytes) {
+    if (!b || (!dst && bytes)) return RT_ERR_INVALID_ARG;
+    rt_ctx ctx = b->ctx;
+    if (bytes > b->bytes) return fail(ctx, RT_ERR_INVALID_ARG, "get_data of %zu bytes from a %zu-byte buffer", bytes, b->bytes);
+    int rc = useDevice(ctx);
+    if (rc) return rc;
+    if (b->layout == LAYOUT_AOS) {
+        HIP_TRY(ctx, hipMemcpyAsync(dst, b->dev, bytes, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        return RT_OK;
+    }
+    void* tmp = nullptr;
+    HIP_TRY(ctx, hipMalloc(&tmp, b->bytes));
+    hipLaunchKernelGGL(k_planes_to_aos, dim3((unsigned)((b->count + 255) / 256)), dim3(256), 0, ctx->stream, planesOf(b), (float*)tmp,
+                       b->layout == LAYOUT_RESERVOIR_PLANES ? 0 : 1);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipMemcpyAsync(dst, tmp, bytes, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    hipError_t e2 = hipFree(tmp);
+    (void)e2;
+    if (e != hipSuccess) return fail(ctx, RT_ERR_NO_DEVICE, "buffer readback failed: %s", hipGetErrorString(e));
+    return RT_OK;
+}
+
+void rt_buffer_release(rt_buffer b) {
+    if (!b) return;
+    hipError_t e = hipSetDevice(b->ctx->device);
+    e = hipStreamSynchronize(b->ctx->stream);
+    if (b->dev) e = hipFree(b->dev);
+    (void)e;
+    delete b;
+}
+int64_t rt_buffer_count(rt_buffer b) { return b ? b->count : 0; }
+int rt_buffer_stride(rt_buffer b) { return b ? b->stride : 0; }
+
+int rt_texture_create(rt_ctx ctx, int w, int h, rt_format format, rt_texture* out) {
+    if (!ctx || !out) return RT_ERR_INVALID_ARG;
+    *out = nullptr;
+    if (w < 1 || h < 1 || w > 65536 || h > 65536) return fail(ctx, RT_ERR_INVALID_ARG, "texture size %dx%d invalid", w, h);
+    if (format != RT_FORMAT_R32F && format != RT_FORMAT_RGBA32F && format != RT_FORMAT_RGBA8_UNORM) return fail(ctx, RT_ERR_INVALID_ARG, "unknown texture format %d", (int)format);
+    int rc = useDevice(ctx);
+    if (rc) return rc;
+    rt_texture t = new rt_texture_s;
+    t->ctx = ctx; t->w = w; t->h = h; t->format = format;
+    t->bytes = (size_t)w * h * (format == RT_FORMAT_R32F ? 4 : 16);
+    t->dev = nullptr;
+    hipError_t e = hipMalloc(&t->dev, t->bytes);
+    if (e == hipSuccess) e = hipMemsetAsync(t->dev, 0, t->bytes, ctx->stream);
+    if (e != hipSuccess) {
+        if (t->dev) { hipError_t e2 = hipFree(t->dev); (void)e2; }
+        delete t;
+        return fail(ctx, e == hipErrorOutOfMemory ? RT_ERR_OUT_OF_MEMORY : RT_ERR_NO_DEVICE, "texture allocation failed: %s", hipGetErrorString(e));
+    }
+    *out = t;
+    return RT_OK;
+}
+
+int rt_texture_set_data(rt_texture t, const void* src, size_t bytes) {
+    if (!t || !src) return RT_ERR_INVALID_ARG;
+    rt_ctx ctx = t->ctx;
+    int rc = useDevice(ctx);
+    if (rc) return rc;
+    const int64_t n = (int64_t)t->w * t->h;
+    if (t->format == RT_FORMAT_RGBA8_UNORM) {
+        if (bytes != (size_t)n * 4) return fail(ctx, RT_ERR_INVALID_ARG, "RGBA8 texture upload must be %lld bytes", (long long)n * 4);
+        void* tmp = nullptr;
+        HIP_TRY(ctx, hipMalloc(&tmp, bytes));
+        hipError_t e = hipMemcpyAsync(tmp, src, bytes, hipMemcpyHostToDevice, ctx->stream);
+        if (e == hipSuccess) {
+            hipLaunchKernelGGL(k_rgba8_to_f32, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, (const uint8_t*)tmp, (float4*)t->dev, n);
+            e = hipGetLastError();
+        }
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        hipError_t e2 = hipFree(tmp);
+        (void)e2;
+        if (e != hipSuccess) return fail(ctx, RT_ERR_NO_DEVICE, "texture upload failed: %s", hipGetErrorString(e));
+        return RT_OK;
+    }
+    if (bytes != t->bytes) return fail(ctx, RT_ERR_INVALID_ARG, "texture upload must be %zu bytes", t->bytes);
+    HIP_TRY(ctx, hipMemcpyAsync(t->dev, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return RT_OK;
+}
+
+int rt_texture_get_data(rt_texture t, void* dst, size_t bytes) {
+    if (!t || !dst) return RT_ERR_INVALID_ARG;
+    rt_ctx ctx = t->ctx;
+    if (bytes > t->bytes) return fail(ctx, RT_ERR_INVALID_ARG, "texture readback of %zu bytes from %zu", bytes, t->bytes);
+    int rc = useDevice(ctx);
+    if (rc) return rc;
+    HIP_TRY(ctx, hipMemcpyAsync(dst, t->dev, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return RT_OK;
+}
+
+void rt_texture_release(rt_texture t) {
+    if (!t) return;
+    hipError_t e = hipSetDevice(t->ctx->device);
+    e = hipStreamSynchronize(t->ctx->stream);
+    if (t->dev) e = hipFree(t->dev);
+    (void)e;
+    delete t;
+}
+
+int rt_enable_stats(rt_ctx ctx, int level) {
+    if (!ctx || level < 0 || level > 2) return RT_ERR_INVALID_ARG;
+    ctx->statsLevel = level;
+    return RT_OK;
+}
+int rt_get_stats(rt_shader sh, int kernel, rt_dispatch_stats* out) {
+    if (!sh || !out || kernel < 0 || kernel >= 8) return RT_ERR_INVALID_ARG;
+    rt_ctx ctx = sh->ctx;
+    int rc = useDevice(ctx);
+    if (rc) return rc;
+    unsigned long long h[8];
+    HIP_TRY(ctx, hipMemcpyAsync(h, sh->statsDev + kernel * 8, sizeof h, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipMemsetAsync(sh->statsDev + kernel * 8, 0, sizeof h, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    out->rays = h[ST_RAYS]; out->pops = h[ST_POPS]; out->bvChecks = h[ST_BVCHECKS]; out->objVisits = h[ST_OBJVISITS];
+    out->triIters = h[ST_TRIITERS]; out->triChecks = h[ST_TRICHECKS]; out->validNeighbours = h[ST_NEIGHBOURS];
+    out->activePixels = h[ST_ACTIVE];
+    return RT_OK;
+}
+
+}  // extern "C"

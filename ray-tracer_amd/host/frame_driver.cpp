@@ -1,0 +1,449 @@
+// frame_driver.cpp — C++ restatement of the reference's frame driver, talking to the GPU only through the C-ABI.
+//
+// Class and method names follow the C# they restate so the two can be read side by side:
+//   Main            BVH_ReSTIR_DL/Assets/Scripts/Main.cs
+//   ShaderHelper    BVH_ReSTIR_DL/Assets/Scripts/ShaderHelper.cs
+//   ComputeHelper   BVH_ReSTIR_DL/Assets/Scripts/ComputeHelper.cs
+// ComputeShader / ComputeBuffer / RenderTexture below are thin wrappers over include/rt_native.h with Unity's
+// method names: the same substitution a C# host would make with a P/Invoke shim.
+#include "rth_api.h"
+#include "unity_math.h"
+
+#include <cmath>
+#include <cstdio>
+#include <map>
+#include <string>
+#include <vector>
+
+namespace {
+
+struct int2 { int x, y; };
+
+struct DriverError {
+    std::string msg;
+};
+
+// ---- Unity-shaped wrappers over the C-ABI ---------------------------------------------------------------------
+struct ComputeBuffer {
+    rt_buffer h = nullptr;
+    void Release() { rt_buffer_release(h); h = nullptr; }
+};
+struct RenderTexture {
+    rt_texture h = nullptr;
+    void Release() { rt_texture_release(h); h = nullptr; }
+};
+struct ComputeShader {
+    rt_shader h = nullptr;
+    rt_ctx ctx = nullptr;
+    void check(int rc, const char* what) const {
+        if (rc < 0) throw DriverError{std::string(what) + ": " + rt_last_error(ctx)};
+    }
+    void SetInt(const char* n, int v) { check(rt_set_int(h, n, v), n); }
+    void SetFloat(const char* n, float v) { check(rt_set_float(h, n, v), n); }
+    void SetBool(const char* n, bool v) { check(rt_set_bool(h, n, v ? 1 : 0), n); }
+    void SetInts(const char* n, const int* v, int c) { check(rt_set_ints(h, n, v, c), n); }
+    void SetVector(const char* n, float x, float y, float z = 0, float w = 0) {
+        float v[4] = {x, y, z, w};
+        check(rt_set_vector(h, n, v), n);
+    }
+    void SetMatrix(const char* n, const M4& m) { check(rt_set_matrix(h, n, m.m), n); }
+    void SetBuffer(int k, const char* n, const ComputeBuffer& b) { check(rt_set_buffer(h, k, n, b.h), n); }
+    void SetTexture(int k, const char* n, const RenderTexture& t) { check(rt_set_texture(h, k, n, t.h), n); }
+    void EnableKeyword(const char* k) { check(rt_enable_keyword(h, k), k); }
+    void DisableKeyword(const char* k) { check(rt_disable_keyword(h, k), k); }
+    int FindKernel(const char* n) { int k = rt_find_kernel(h, n); check(k, n); return k; }
+    void Dispatch(int k, int gx, int gy, int gz) { check(rt_dispatch(h, k, gx, gy, gz), "Dispatch"); }
+};
+
+// ---- ComputeHelper.cs / Resources.cs ----------------------------------------------------------------------------
+namespace Utils {
+int GetThreadGroupsNum(int threadsNum, int threadSize) { return (int)std::ceil((float)threadsNum / threadSize); }  // Resources.cs:16-20
+}
+namespace ComputeHelper {
+void DispatchKernel(ComputeShader& cs, const char* kernelName, int threadsNum, int threadSize) {  // ComputeHelper.cs:13-17
+    cs.Dispatch(cs.FindKernel(kernelName), Utils::GetThreadGroupsNum(threadsNum, threadSize), 1, 1);
+}
+void DispatchKernel(ComputeShader& cs, const char* kernelName, int2 threadsNum, int threadSize) {  // :20-24
+    cs.Dispatch(cs.FindKernel(kernelName), Utils::GetThreadGroupsNum(threadsNum.x, threadSize),
+                Utils::GetThreadGroupsNum(threadsNum.y, threadSize), 1);
+}
+ComputeBuffer CreateStructuredBuffer(rt_ctx ctx, const void* data, int64_t length, int stride) {  // :73-78
+    ComputeBuffer b;
+    int rc = rt_buffer_create(ctx, length > 1 ? length : 1, stride, &b.h);
+    if (rc < 0) throw DriverError{std::string("CreateStructuredBuffer: ") + rt_last_error(ctx)};
+    if (length > 0) {
+        rc = rt_buffer_set_data(b.h, data, (size_t)length * stride);
+        if (rc < 0) throw DriverError{std::string("SetData: ") + rt_last_error(ctx)};
+    }
+    return b;
+}
+ComputeBuffer CreateStructuredBuffer(rt_ctx ctx, int64_t count, int stride) {  // :96-100
+    ComputeBuffer b;
+    int rc = rt_buffer_create(ctx, count, stride, &b.h);
+    if (rc < 0) throw DriverError{std::string("CreateStructuredBuffer: ") + rt_last_error(ctx)};
+    return b;
+}
+}  // namespace ComputeHelper
+
+RenderTexture CreateTexture(rt_ctx ctx, int2 res, rt_format fmt) {  // TextureHelper.cs:118-156, Main.cs:359
+    RenderTexture t;
+    int rc = rt_texture_create(ctx, res.x, res.y, fmt, &t.h);
+    if (rc < 0) throw DriverError{std::string("CreateTexture: ") + rt_last_error(ctx)};
+    return t;
+}
+
+}  // namespace
+
+// ---- Main.cs -----------------------------------------------------------------------------------------------------
+struct rth_main_s {
+    rt_ctx ctx = nullptr;
+    rth_main_config cfg;
+    rth_scene_data scene;
+    std::string err;
+
+    ComputeShader rtShader, ppShader, pcShader;
+    int FrameCount = 0;
+    int framesStarted = 0;  // UpdatePerFrame calls since Start, selects FrameRand
+    const int RayTracerThreadSize = 8, PostProcesserThreadSize = 8, PreCalcThreadSize = 256;  // Main.cs:64-66
+
+    ComputeBuffer BVBuffer, RenderTriangleBuffer, VertexBuffer, SceneObjectDataBuffer, LightObjectBuffer, MaterialBuffer;
+    ComputeBuffer CandidateBuffer, CandidateReuseBuffer, TemporalFrameBuffer, HitInfoBuffer;
+    RenderTexture RTResultTexture, AccumulatedResultTexture, DebugOverlayTexture, RayHitPointATexture, RayHitPointBTexture,
+        DepthBufferTexture, NormalsBufferTexture, TextureAtlas, EnvironmentMapTexture;
+    bool texturesCreated = false;
+    bool haveLastCamera = false;
+    float lastWorldSpaceCameraPos[3];
+    M4 lastCameraTransform;
+
+    int2 Resolution() const { return {cfg.Resolution[0], cfg.Resolution[1]}; }
+
+    // ShaderHelper.cs:7-73
+    void SetMaterialBuffer() { rtShader.SetBuffer(0, "Materials", MaterialBuffer); rtShader.SetBuffer(4, "Materials", MaterialBuffer); }
+    void SetTriBuffer() {
+        rtShader.SetBuffer(0, "Triangles", RenderTriangleBuffer);
+        rtShader.SetBuffer(4, "Triangles", RenderTriangleBuffer);
+        pcShader.SetBuffer(0, "Triangles", RenderTriangleBuffer);
+        pcShader.SetInt("TrianglesNum", (int)scene.nTriangles);
+        rtShader.SetInt("TrianglesNum", (int)scene.nTriangles);
+    }
+    void SetVertexBuffer() {
+        rtShader.SetBuffer(0, "Vertices", VertexBuffer);
+        rtShader.SetBuffer(4, "Vertices", VertexBuffer);
+        pcShader.SetBuffer(0, "Vertices", VertexBuffer);
+    }
+    void SetBVBuffer() {
+        rtShader.SetBuffer(0, "BVs", BVBuffer);
+        rtShader.SetBuffer(4, "BVs", BVBuffer);
+        rtShader.SetInt("BVsNum", (int)scene.nBVs);
+    }
+    void SetSceneObjectDataBuffer() {
+        rtShader.SetBuffer(0, "SceneObjects", SceneObjectDataBuffer);
+        rtShader.SetBuffer(4, "SceneObjects", SceneObjectDataBuffer);
+        pcShader.SetBuffer(0, "SceneObjects", SceneObjectDataBuffer);
+        rtShader.SetInt("SceneObjectsNum", (int)scene.nSceneObjects);
+    }
+    void SetLightObjectBuffer() { rtShader.SetBuffer(0, "LightObjects", LightObjectBuffer); }
+    void SetCandidateBuffer() { for (int k = 0; k < 5; k++) rtShader.SetBuffer(k, "Candidates", CandidateBuffer); }
+    void SetCandidateReuseBuffer() { rtShader.SetBuffer(1, "CandidatesB", CandidateReuseBuffer); rtShader.SetBuffer(2, "CandidatesB", CandidateReuseBuffer); }
+    void SetTemporalFrameBuffer() { rtShader.SetBuffer(3, "TemporalFrameBuffer", TemporalFrameBuffer); rtShader.SetBuffer(4, "TemporalFrameBuffer", TemporalFrameBuffer); }
+    void SetHitInfoBuffer() { rtShader.SetBuffer(0, "HitInfos", HitInfoBuffer); rtShader.SetBuffer(4, "HitInfos", HitInfoBuffer); }
+
+    // Main.cs:134-145
+    void UpdatePerFrame() {
+        int FrameRand = (int)(((uint64_t)cfg.frameRandBase + (uint64_t)cfg.frameRandStep * (uint64_t)framesStarted) % 999999u);
+        framesStarted++;
+        rtShader.SetInt("FrameRand", FrameRand);
+        rtShader.SetInt("FrameCount", FrameCount);
+        ppShader.SetInt("FrameCount", FrameCount);
+        FrameCount++;
+        SetCameraData();
+    }
+    // Main.cs:184-204
+    void SetCameraData() {
+        const float* worldSpaceCameraPos = cfg.cameraPosition;
+        if (!haveLastCamera) memcpy(lastWorldSpaceCameraPos, worldSpaceCameraPos, 12);
+        rtShader.SetVector("WorldSpaceCameraPos", worldSpaceCameraPos[0], worldSpaceCameraPos[1], worldSpaceCameraPos[2]);
+        rtShader.SetVector("LastWorldSpaceCameraPos", lastWorldSpaceCameraPos[0], lastWorldSpaceCameraPos[1], lastWorldSpaceCameraPos[2]);
+        M4 cameraTransform, unusedInverse;
+        rth_camera_matrices(cfg.cameraPosition, cfg.cameraRotation, cameraTransform.m, unusedInverse.m);
+        if (!haveLastCamera) lastCameraTransform = cameraTransform;
+        rtShader.SetMatrix("CameraTransform", cameraTransform);
+        rtShader.SetMatrix("LastCameraTransformInverse", inverse(lastCameraTransform));
+        memcpy(lastWorldSpaceCameraPos, worldSpaceCameraPos, 12);
+        lastCameraTransform = cameraTransform;
+        haveLastCamera = true;
+    }
+    // Main.cs:211-271
+    void UpdateSettings(bool resetBufferData) {
+        FrameCount = 0;
+        if (resetBufferData) SetData();
+        int resolutionArray[2] = {cfg.Resolution[0], cfg.Resolution[1]};
+        rtShader.SetInts("Resolution", resolutionArray, 2);
+        rtShader.SetInt("MaxBounceCount", cfg.MaxBounceCount);
+        rtShader.SetFloat("ScatterProbability", cfg.ScatterProbability);
+        float viewSpaceDims[2];
+        rth_view_space_dims(cfg.fieldOfView, cfg.Resolution[0], cfg.Resolution[1], viewSpaceDims);
+        rtShader.SetVector("ViewSpaceDims", viewSpaceDims[0], viewSpaceDims[1]);
+        rtShader.SetFloat("DefocusStrength", cfg.DefocusStrength);
+        rtShader.SetFloat("FocalPlaneFactor", cfg.FocalPlaneFactor);
+        int DebugDataMaxValues[2] = {cfg.DebugMaxTriChecks, cfg.DebugMaxBVChecks};
+        rtShader.SetInts("DebugDataMaxValues", DebugDataMaxValues, 2);
+        rtShader.SetInt("SceneObjectReservoirTestsNum", cfg.SceneObjectReservoirTestsNum);
+        rtShader.SetInt("TriReservoirTestsNum", cfg.TriReservoirTestsNum);
+        rtShader.SetInt("CandidateReservoirTestsNum", cfg.CandidateReservoirTestsNum);
+        rtShader.SetFloat("TemporalReuseWeight", cfg.TemporalReuseWeight);
+        rtShader.SetFloat("PixelMovementThreshold", cfg.PixelMovementThreshold);
+        rtShader.SetFloat("SpatialHitPointDiffThreshold", cfg.SpatialHitPointDiffThreshold);
+        rtShader.SetFloat("SpatialNormalsAngleThreshold", cfg.SpatialNormalsAngleThreshold);
+        rtShader.SetFloat("SpatialBRDFThreshold", cfg.SpatialBRDFThreshold);
+        rtShader.SetInt("TemporalCandidatesNum", cfg.TemporalCandidatesNum);
+        rtShader.SetFloat("TemporalPrecisionThreshold", cfg.TemporalPrecisionThreshold);
+        rtShader.SetFloat("VisibilityReuseThreshold", cfg.VisibilityReuseThreshold);
+        if (cfg.DoVisibilityReuse) rtShader.EnableKeyword("VIS_REUSE"); else rtShader.DisableKeyword("VIS_REUSE");
+        if (cfg.DoWeightRecalc) rtShader.EnableKeyword("WEIGHT_RECALC"); else rtShader.DisableKeyword("WEIGHT_RECALC");
+        if (cfg.DoBRDF) rtShader.EnableKeyword("BRDF"); else rtShader.DisableKeyword("BRDF");
+        // Object textures: the committed scene's materials carry no usable texture (its one normal map is not in the
+        // snapshot), so the atlas is a 1x1 black texel and the environment map a 1x1 sky colour.
+        int textureAtlasDims[2] = {1, 1};
+        rtShader.SetInts("TextureAtlasDims", textureAtlasDims, 2);
+        rtShader.SetTexture(0, "TextureAtlas", TextureAtlas);
+        rtShader.SetTexture(4, "TextureAtlas", TextureAtlas);
+        int environmentMapTexDims[2] = {1, 1};
+        rtShader.SetInts("EnvironmentMapTexDims", environmentMapTexDims, 2);
+        rtShader.SetTexture(4, "EnvironmentMap", EnvironmentMapTexture);
+    }
+    // Main.cs:273-310 (+ ObjectHelper.ConstructScene's SetInt/SetFloat calls, ObjectHelper.cs:637,647,686,696)
+    void SetData() {
+        rtShader.SetInt("MaxBVHDepth", scene.maxBVHDepth);
+        rtShader.SetFloat("TotArea", scene.totArea);
+        rtShader.SetInt("SceneBVHStartIndex", scene.sceneBVHStartIndex);
+        rtShader.SetInt("EmittingObjectsNum", scene.emittingObjectsNum);
+        if (!TextureAtlas.h) {
+            TextureAtlas = CreateTexture(ctx, {1, 1}, RT_FORMAT_RGBA8_UNORM);
+            EnvironmentMapTexture = CreateTexture(ctx, {1, 1}, RT_FORMAT_RGBA32F);
+            const float sky[4] = {0.5f, 0.7f, 1.0f, 1.0f};
+            int rc = rt_texture_set_data(EnvironmentMapTexture.h, sky, sizeof sky);
+            if (rc < 0) throw DriverError{std::string("EnvironmentMap upload: ") + rt_last_error(ctx)};
+        }
+        MaterialBuffer = ComputeHelper::CreateStructuredBuffer(ctx, scene.Materials, scene.nMaterials, sizeof(rt_material));
+        SetMaterialBuffer();
+        BVBuffer = ComputeHelper::CreateStructuredBuffer(ctx, scene.BVs, scene.nBVs, sizeof(rt_bv));
+        SetBVBuffer();
+        SceneObjectDataBuffer = ComputeHelper::CreateStructuredBuffer(ctx, scene.SceneObjects, scene.nSceneObjects, sizeof(rt_scene_object));
+        SetSceneObjectDataBuffer();
+        RenderTriangleBuffer = ComputeHelper::CreateStructuredBuffer(ctx, scene.Triangles, scene.nTriangles, sizeof(rt_triangle));
+        SetTriBuffer();
+        VertexBuffer = ComputeHelper::CreateStructuredBuffer(ctx, scene.Vertices, scene.nVertices, sizeof(rt_vertex));
+        SetVertexBuffer();
+        RunPreCalcShader();
+        LightObjectBuffer = ComputeHelper::CreateStructuredBuffer(ctx, scene.LightObjects, scene.nLightObjects, sizeof(rt_light_object));
+        SetLightObjectBuffer();
+        int64_t npx = (int64_t)cfg.Resolution[0] * cfg.Resolution[1];
+        CandidateBuffer = ComputeHelper::CreateStructuredBuffer(ctx, npx, sizeof(rt_reservoir));
+        SetCandidateBuffer();
+        CandidateReuseBuffer = ComputeHelper::CreateStructuredBuffer(ctx, npx, sizeof(rt_reservoir));
+        SetCandidateReuseBuffer();
+        TemporalFrameBuffer = ComputeHelper::CreateStructuredBuffer(ctx, npx, sizeof(rt_reservoir));
+        SetTemporalFrameBuffer();
+        HitInfoBuffer = ComputeHelper::CreateStructuredBuffer(ctx, npx, sizeof(rt_hit_info));
+        SetHitInfoBuffer();
+    }
+    // Main.cs:312-380
+    void CreateTextures() {
+        if (texturesCreated) return;
+        RTResultTexture = CreateTexture(ctx, Resolution(), RT_FORMAT_RGBA32F);
+        rtShader.SetTexture(4, "Result", RTResultTexture);
+        ppShader.SetTexture(0, "Result", RTResultTexture);
+        AccumulatedResultTexture = CreateTexture(ctx, Resolution(), RT_FORMAT_RGBA32F);
+        ppShader.SetTexture(0, "AccumulatedResult", AccumulatedResultTexture);
+        DebugOverlayTexture = CreateTexture(ctx, Resolution(), RT_FORMAT_RGBA32F);
+        rtShader.SetTexture(0, "DebugOverlay", DebugOverlayTexture);
+        rtShader.SetTexture(3, "DebugOverlay", DebugOverlayTexture);
+        RayHitPointATexture = CreateTexture(ctx, Resolution(), RT_FORMAT_RGBA32F);
+        rtShader.SetTexture(0, "RayHitPointsA", RayHitPointATexture);
+        rtShader.SetTexture(3, "RayHitPointsA", RayHitPointATexture);
+        RayHitPointBTexture = CreateTexture(ctx, Resolution(), RT_FORMAT_RGBA32F);
+        rtShader.SetTexture(0, "RayHitPointsB", RayHitPointBTexture);
+        rtShader.SetTexture(3, "RayHitPointsB", RayHitPointBTexture);
+        DepthBufferTexture = CreateTexture(ctx, Resolution(), RT_FORMAT_R32F);
+        for (int k = 0; k < 4; k++) rtShader.SetTexture(k, "DepthBuffer", DepthBufferTexture);
+        NormalsBufferTexture = CreateTexture(ctx, Resolution(), RT_FORMAT_RGBA32F);
+        rtShader.SetTexture(0, "NormalsBuffer", NormalsBufferTexture);
+        rtShader.SetTexture(1, "NormalsBuffer", NormalsBufferTexture);
+        texturesCreated = true;
+    }
+    void RunPreCalcShader() { ComputeHelper::DispatchKernel(pcShader, "CalcTriNormals", (int)scene.nTriangles, PreCalcThreadSize); }  // :382-385
+    // Main.cs:387-402
+    void SpatialReuse() {
+        bool reuseBufferCycle = false;
+        for (int i = 0; i < cfg.SpatialReuseIterations; i++) {
+            reuseBufferCycle = !reuseBufferCycle;
+            int maxOffset = (int)(float)pow(3.0, (double)i) * cfg.SpatialReuseBlur;  // (int)Mathf.Pow(3, i)
+            rtShader.SetInt("MaxOffset", maxOffset);
+            rtShader.SetBool("ReuseBufferCycle", reuseBufferCycle);
+            ComputeHelper::DispatchKernel(rtShader, "SpatialReusePass", Resolution(), RayTracerThreadSize);
+        }
+        if (reuseBufferCycle == true) ComputeHelper::DispatchKernel(rtShader, "TransferToOriginal", Resolution(), RayTracerThreadSize);
+    }
+    // Main.cs:404-415
+    void RunReSTIRShader() {
+        CreateTextures();
+        ComputeHelper::DispatchKernel(rtShader, "InitialTrace", Resolution(), RayTracerThreadSize);
+        if (cfg.TemporalReuseWeight > 0) ComputeHelper::DispatchKernel(rtShader, "TemporalReuse", Resolution(), RayTracerThreadSize);
+        if (cfg.SpatialReuseIterations > 0) SpatialReuse();
+        ComputeHelper::DispatchKernel(rtShader, "TraceRays", Resolution(), RayTracerThreadSize);
+    }
+    void RunStage(int stage) {
+        CreateTextures();
+        switch (stage) {
+            case 0: ComputeHelper::DispatchKernel(rtShader, "InitialTrace", Resolution(), RayTracerThreadSize); break;
+            case 1: if (cfg.TemporalReuseWeight > 0) ComputeHelper::DispatchKernel(rtShader, "TemporalReuse", Resolution(), RayTracerThreadSize); break;
+            case 2: if (cfg.SpatialReuseIterations > 0) SpatialReuse(); break;
+            case 3: ComputeHelper::DispatchKernel(rtShader, "TraceRays", Resolution(), RayTracerThreadSize); break;
+            default: throw DriverError{"unknown stage"};
+        }
+    }
+    void RunPostProcessingShader() { ComputeHelper::DispatchKernel(ppShader, "AccumulateFrames", Resolution(), PostProcesserThreadSize); }  // :417-420
+    // Main.cs:105-115
+    void Start() {
+        UpdatePerFrame();
+        UpdateSettings(true);
+        SetCameraData();
+        framesStarted = 0;  // FrameRand numbering starts with the first rendered frame
+    }
+    void ReleaseAll() {  // Main.cs:507-513
+        ComputeBuffer* bufs[] = {&BVBuffer, &RenderTriangleBuffer, &VertexBuffer, &SceneObjectDataBuffer, &LightObjectBuffer, &MaterialBuffer,
+                                 &CandidateBuffer, &CandidateReuseBuffer, &TemporalFrameBuffer, &HitInfoBuffer};
+        for (auto* b : bufs) b->Release();
+        RenderTexture* texs[] = {&RTResultTexture, &AccumulatedResultTexture, &DebugOverlayTexture, &RayHitPointATexture, &RayHitPointBTexture,
+                                 &DepthBufferTexture, &NormalsBufferTexture, &TextureAtlas, &EnvironmentMapTexture};
+        for (auto* t : texs) t->Release();
+        rt_shader_close(rtShader.h); rt_shader_close(ppShader.h); rt_shader_close(pcShader.h);
+        rtShader.h = ppShader.h = pcShader.h = nullptr;
+    }
+};
+
+namespace {
+template <class F>
+int guarded(rth_main m, F f) {
+    if (!m) return -1;
+    try {
+        f();
+        return 0;
+    } catch (const DriverError& e) {
+        m->err = e.msg;
+        return -1;
+    }
+}
+}  // namespace
+
+extern "C" {
+
+// Main.UpdateSettings, Main.cs:223-228
+void rth_view_space_dims(float fieldOfView, int resX, int resY, float out[2]) {
+    float aspectRatio = (float)(resX / resY);  // integer division, Main.cs:223
+    float fieldOfViewRad = fieldOfView * 3.14159274f / 180;
+    float viewSpaceHeight = (float)tan((double)(fieldOfViewRad * 0.5f));  // Mathf.Tan
+    float viewSpaceWidth = aspectRatio * viewSpaceHeight;
+    out[0] = viewSpaceWidth;
+    out[1] = viewSpaceHeight;
+}
+// transform.localToWorldMatrix and its inverse, Main.cs:194-199
+void rth_camera_matrices(const float position[3], const float rotation[4], float outTransform[16], float outInverse[16]) {
+    M4 t = fromPositionRotation(position, rotation);
+    M4 i = inverse(t);
+    memcpy(outTransform, t.m, 64);
+    memcpy(outInverse, i.m, 64);
+}
+
+void rth_main_default_config(rth_main_config* c) {
+    if (!c) return;
+    memset(c, 0, sizeof *c);
+    c->Resolution[0] = 1920; c->Resolution[1] = 1080;
+    c->fieldOfView = 70;
+    c->MaxBounceCount = 1;
+    c->ScatterProbability = 1; c->DefocusStrength = 0; c->FocalPlaneFactor = 1;
+    c->DebugMaxTriChecks = 10; c->DebugMaxBVChecks = 100;
+    c->SceneObjectReservoirTestsNum = 5; c->TriReservoirTestsNum = 5; c->CandidateReservoirTestsNum = 5;
+    c->SpatialReuseIterations = 3; c->TemporalCandidatesNum = 9; c->SpatialReuseBlur = 3;
+    c->TemporalPrecisionThreshold = 0.000001f; c->TemporalReuseWeight = 0.9f; c->PixelMovementThreshold = 1;
+    c->SpatialHitPointDiffThreshold = 0.5f; c->SpatialNormalsAngleThreshold = 360; c->SpatialBRDFThreshold = 999;
+    c->VisibilityReuseThreshold = 5;
+    c->DoVisibilityReuse = 1; c->DoWeightRecalc = 0; c->DoBRDF = 1;
+    c->cameraPosition[0] = 10; c->cameraPosition[1] = 3; c->cameraPosition[2] = 7;
+    c->cameraRotation[0] = 0; c->cameraRotation[1] = -0.5150381f; c->cameraRotation[2] = 0; c->cameraRotation[3] = 0.85716736f;
+    c->frameRandBase = 12345; c->frameRandStep = 7919;
+}
+
+rth_main rth_main_create(rt_ctx ctx, const rth_main_config* cfg, rth_scene scene, int row0, int row1) {
+    if (!ctx || !cfg || !scene) return nullptr;
+    rth_main m = new rth_main_s;
+    m->ctx = ctx;
+    m->cfg = *cfg;
+    if (rth_scene_get(scene, &m->scene) != 0) { delete m; return nullptr; }
+    if (cfg->Resolution[0] < 1 || cfg->Resolution[1] < 1) { delete m; return nullptr; }
+    int rc = guarded(m, [&] {
+        m->rtShader.ctx = m->ppShader.ctx = m->pcShader.ctx = ctx;
+        if (rt_set_row_band(ctx, row0, row1) < 0) throw DriverError{rt_last_error(ctx)};
+        if (rt_shader_open(ctx, "ReSTIR_BVH_RayTracer", &m->rtShader.h) < 0) throw DriverError{rt_last_error(ctx)};
+        if (rt_shader_open(ctx, "PostProcessor", &m->ppShader.h) < 0) throw DriverError{rt_last_error(ctx)};
+        if (rt_shader_open(ctx, "PreCalc", &m->pcShader.h) < 0) throw DriverError{rt_last_error(ctx)};
+        m->Start();
+    });
+    if (rc != 0) {
+        fprintf(stderr, "rth_main_create: %s\n", m->err.c_str());
+        m->ReleaseAll();
+        delete m;
+        return nullptr;
+    }
+    return m;
+}
+void rth_main_destroy(rth_main m) {
+    if (!m) return;
+    m->ReleaseAll();
+    delete m;
+}
+const char* rth_main_last_error(rth_main m) { return m ? m->err.c_str() : "null driver"; }
+
+int rth_main_update_per_frame(rth_main m) { return guarded(m, [&] { m->UpdatePerFrame(); }); }
+int rth_main_run_restir_shader(rth_main m) { return guarded(m, [&] { m->RunReSTIRShader(); }); }
+int rth_main_run_post_processing(rth_main m) { return guarded(m, [&] { m->RunPostProcessingShader(); }); }
+int rth_main_run_stage(rth_main m, int stage) { return guarded(m, [&] { m->RunStage(stage); }); }
+int rth_main_render_frame(rth_main m) {
+    return guarded(m, [&] {
+        m->UpdatePerFrame();
+        m->RunReSTIRShader();
+        m->RunPostProcessingShader();
+    });
+}
+int rth_main_frame_count(rth_main m) { return m ? m->FrameCount : -1; }
+
+rt_buffer rth_main_buffer(rth_main m, const char* name) {
+    if (!m || !name) return nullptr;
+    std::map<std::string, ComputeBuffer*> t = {{"BVs", &m->BVBuffer}, {"Triangles", &m->RenderTriangleBuffer}, {"Vertices", &m->VertexBuffer},
+        {"SceneObjects", &m->SceneObjectDataBuffer}, {"LightObjects", &m->LightObjectBuffer}, {"Materials", &m->MaterialBuffer},
+        {"Candidates", &m->CandidateBuffer}, {"CandidatesB", &m->CandidateReuseBuffer}, {"TemporalFrameBuffer", &m->TemporalFrameBuffer},
+        {"HitInfos", &m->HitInfoBuffer}};
+    auto it = t.find(name);
+    return it == t.end() ? nullptr : it->second->h;
+}
+rt_texture rth_main_texture(rth_main m, const char* name) {
+    if (!m || !name) return nullptr;
+    int rc = guarded(m, [&] { m->CreateTextures(); });
+    if (rc != 0) return nullptr;
+    std::map<std::string, RenderTexture*> t = {{"Result", &m->RTResultTexture}, {"AccumulatedResult", &m->AccumulatedResultTexture},
+        {"DebugOverlay", &m->DebugOverlayTexture}, {"DepthBuffer", &m->DepthBufferTexture}, {"NormalsBuffer", &m->NormalsBufferTexture},
+        {"RayHitPointsA", &m->RayHitPointATexture}, {"RayHitPointsB", &m->RayHitPointBTexture}, {"TextureAtlas", &m->TextureAtlas},
+        {"EnvironmentMap", &m->EnvironmentMapTexture}};
+    auto it = t.find(name);
+    return it == t.end() ? nullptr : it->second->h;
+}
+rt_shader rth_main_shader(rth_main m, const char* name) {
+    if (!m || !name) return nullptr;
+    if (!strcmp(name, "rt")) return m->rtShader.h;
+    if (!strcmp(name, "pp")) return m->ppShader.h;
+    if (!strcmp(name, "pc")) return m->pcShader.h;
+    return nullptr;
+}
+
+}  // extern "C"

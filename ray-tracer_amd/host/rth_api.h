@@ -1,0 +1,140 @@
+/* rth_api.h — C interface of librthost.so: the host side that sits ABOVE the C-ABI of librtnative.so.
+ *
+ * In the reference the host side is Unity C#.  This library restates, in C++, the parts of it that feed and
+ * drive the compute path, so the path can run and be measured headless:
+ *   - the scene/BVH builder  (BVH_ReSTIR_DL/Assets/Scripts/ObjectHelper.cs, Resources.cs, Data types/Other/)
+ *   - the frame driver       (BVH_ReSTIR_DL/Assets/Scripts/Main.cs, ShaderHelper.cs, ComputeHelper.cs)
+ * The frame driver only ever talks to the GPU through include/rt_native.h, exactly as the C# would through
+ * P/Invoke.  Python (tests, bench.py) binds this interface with ctypes.
+ */
+#ifndef RTH_API_H
+#define RTH_API_H
+
+#include "../../include/rt_native.h"
+#include "../../include/rt_types.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ------------------------------------------------ meshes ------------------------------------------------ */
+typedef struct rth_mesh_s* rth_mesh;
+
+rth_mesh rth_mesh_create(const rt_vertex* verts, int nverts, const int32_t* tris, int ntris);
+/* Loads the .rtmesh format written by tools/import_obj.py.  NULL on failure. */
+rth_mesh rth_mesh_load(const char* path);
+/* Splits every triangle into 9 by trisecting its edges (shared edges share the new vertices).  New mesh. */
+rth_mesh rth_mesh_subdivide9(rth_mesh m);
+/* Returns a copy whose vertex positions are displaced by a seeded pseudo-random offset of at most `amplitude`
+ * per axis, so that otherwise identical meshes are distinct geometry. */
+rth_mesh rth_mesh_jitter(rth_mesh m, uint32_t seed, float amplitude);
+/* Procedural fan of `ntris` triangles around the z axis (unit radius), facing +z.  Used for emissive quads/discs. */
+rth_mesh rth_mesh_disc(int ntris);
+void rth_mesh_free(rth_mesh m);
+int rth_mesh_counts(rth_mesh m, int* nverts, int* ntris);
+const rt_vertex* rth_mesh_vertices(rth_mesh m);
+const int32_t* rth_mesh_triangles(rth_mesh m);
+
+/* ------------------------------------------------ scene ------------------------------------------------- */
+typedef struct rth_scene_s* rth_scene;
+
+/* MaterialInput (Data types/Other/MaterialInput.cs) without textures: the scalar path of ConstructTextureAtlas
+ * (ObjectHelper.cs:390-449). */
+typedef struct {
+    float brightness;
+    float col[3];
+    float roughness;
+    float metallicity;
+    float bump;
+} rth_material_input;
+
+/* splitResolution, maxDepthSceneBVH: ObjectHelper.SplitResolution / MaxDepthSceneBVH (ObjectHelper.cs:19-20). */
+rth_scene rth_scene_create(int splitResolution, int maxDepthSceneBVH);
+void rth_scene_free(rth_scene s);
+/* Returns the material index. */
+int rth_scene_add_material(rth_scene s, const rth_material_input* m);
+/* Registers a mesh (copied) and returns its mesh id.  Objects that share a mesh id share one BVH, which is
+ * what the reference's mesh-key lookup does (ObjectHelper.cs:582-594). */
+int rth_scene_add_mesh(rth_scene s, rth_mesh m);
+/* A GameObject: transform (position, Euler angles in degrees, scale) + SceneObjectSettings.{MaterialIndex,MaxDepthBVH}. */
+int rth_scene_add_object(rth_scene s, int meshId, const float position[3], const float eulerDeg[3],
+                         const float scale[3], int materialIndex, int maxDepthBVH);
+/* ObjectHelper.ConstructScene (ObjectHelper.cs:666-738) on the registered objects.  threads <= 0: all cores. */
+int rth_scene_build(rth_scene s, int threads);
+
+typedef struct {
+    const rt_bv* BVs; int64_t nBVs;
+    const rt_vertex* Vertices; int64_t nVertices;
+    const rt_triangle* Triangles; int64_t nTriangles;   /* RenderTriangle[] in BVH order, localNormal = 0 */
+    const rt_scene_object* SceneObjects; int64_t nSceneObjects;
+    const rt_light_object* LightObjects; int64_t nLightObjects;
+    const rt_material* Materials; int64_t nMaterials;
+    const rt_int2* ComponentDatas; int64_t nComponentDatas; /* (componentStart, totComponents) per BV node */
+    int32_t maxBVHDepth, emittingObjectsNum, sceneBVHStartIndex;
+    float totArea;
+} rth_scene_data;
+int rth_scene_get(rth_scene s, rth_scene_data* out);
+
+/* Utils.CreateWorldToLocalMatrix (Resources.cs:67-87) and its inverse, column-major. */
+void rth_world_to_local(const float position[3], const float eulerDeg[3], const float scale[3], float outW2L[16],
+                        float outL2W[16]);
+
+/* --------------------------------------------- frame driver --------------------------------------------- */
+/* ViewSpaceDims as Main.UpdateSettings computes it (Main.cs:223-228; the aspect ratio is an integer division). */
+void rth_view_space_dims(float fieldOfView, int resX, int resY, float out[2]);
+/* Camera localToWorld matrix (column-major) from position + rotation quaternion, and its inverse (Main.cs:194-199). */
+void rth_camera_matrices(const float position[3], const float rotation[4], float outTransform[16], float outInverse[16]);
+
+typedef struct rth_main_s* rth_main;
+
+/* The inspector fields of Main (Main.cs:8-53) that reach the compute path, plus the camera transform. */
+typedef struct {
+    int32_t Resolution[2];
+    float fieldOfView;
+    int32_t MaxBounceCount;
+    float ScatterProbability, DefocusStrength, FocalPlaneFactor;
+    int32_t DebugMaxTriChecks, DebugMaxBVChecks;
+    int32_t SceneObjectReservoirTestsNum, TriReservoirTestsNum, CandidateReservoirTestsNum;
+    int32_t SpatialReuseIterations, TemporalCandidatesNum, SpatialReuseBlur;
+    float TemporalPrecisionThreshold, TemporalReuseWeight, PixelMovementThreshold;
+    float SpatialHitPointDiffThreshold, SpatialNormalsAngleThreshold, SpatialBRDFThreshold, VisibilityReuseThreshold;
+    int32_t DoVisibilityReuse, DoWeightRecalc, DoBRDF;
+    float cameraPosition[3];
+    float cameraRotation[4]; /* quaternion x,y,z,w */
+    /* FrameRand for frame k is (frameRandBase + frameRandStep*k) mod 999999; the reference draws
+     * UnityEngine.Random.Range(0, 999999) (Main.cs:137), which is not reproducible. */
+    uint32_t frameRandBase, frameRandStep;
+} rth_main_config;
+
+void rth_main_default_config(rth_main_config* cfg); /* values of the committed Unity scene (Ray Tracer.unity:622-652) */
+
+/* Main.Start (Main.cs:105-115): opens the three shaders on `ctx`, uploads the scene (SetData, :273-310),
+ * pushes all settings (UpdateSettings, :211-271).  The scene must be built.  row0/row1: image rows this context
+ * renders (row1 <= 0: all rows). */
+rth_main rth_main_create(rt_ctx ctx, const rth_main_config* cfg, rth_scene scene, int row0, int row1);
+void rth_main_destroy(rth_main m);
+const char* rth_main_last_error(rth_main m);
+
+/* One Unity frame: Update -> UpdatePerFrame (Main.cs:134-145), then OnRenderImage -> RunReSTIRShader (:404-415)
+ * and RunPostProcessingShader (:417-420).  Asynchronous; returns after enqueueing. */
+int rth_main_render_frame(rth_main m);
+/* The two halves separately, for tests that interleave readbacks: */
+int rth_main_update_per_frame(rth_main m);
+int rth_main_run_restir_shader(rth_main m);
+int rth_main_run_post_processing(rth_main m);
+/* Individual dispatches of RunReSTIRShader, for per-kernel parity tests and timing. stage: 0 InitialTrace,
+ * 1 TemporalReuse, 2 SpatialReuse (all passes + transfer), 3 TraceRays. */
+int rth_main_run_stage(rth_main m, int stage);
+int rth_main_frame_count(rth_main m);
+
+/* Named access to the driver's buffers and textures ("Candidates", "CandidatesB", "TemporalFrameBuffer",
+ * "HitInfos", "Triangles", ...; "Result", "AccumulatedResult", "DebugOverlay", "DepthBuffer", "NormalsBuffer",
+ * "RayHitPointsA", "RayHitPointsB").  NULL if unknown. */
+rt_buffer rth_main_buffer(rth_main m, const char* name);
+rt_texture rth_main_texture(rth_main m, const char* name);
+rt_shader rth_main_shader(rth_main m, const char* name); /* "rt", "pp", "pc" */
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,254 @@
+"""Test-side harness: ctypes binding of the CPU oracle (oracle/librtoracle.so) and an oracle-backed frame loop.
+
+TEST INFRASTRUCTURE.  `OracleRenderer` replays the reference's frame sequence (Main.cs:134-145, 387-420) on the CPU
+oracle with the same constants the C++ frame driver pushes through the C-ABI, so that GPU results can be compared
+buffer by buffer.  Nothing under the product package imports this file.
+"""
+import ctypes as C
+import importlib
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+rt = importlib.import_module("ray-tracer_amd")
+DT = rt.DTYPES
+
+
+class OrcParams(C.Structure):
+    _fields_ = [("TrianglesNum", C.c_uint32), ("BVsNum", C.c_uint32), ("MaxBVHDepth", C.c_uint32),
+                ("SceneBVHStartIndex", C.c_uint32), ("SceneObjectsNum", C.c_uint32), ("ScatterProbability", C.c_float),
+                ("MaxBounceCount", C.c_uint32), ("Resolution", C.c_int32 * 2), ("ViewSpaceDims", C.c_float * 2),
+                ("DefocusStrength", C.c_float), ("FocalPlaneFactor", C.c_float),
+                ("WorldSpaceCameraPos", C.c_float * 3), ("LastWorldSpaceCameraPos", C.c_float * 3),
+                ("CameraTransform", C.c_float * 9), ("LastCameraTransformInverse", C.c_float * 9),
+                ("FrameRand", C.c_uint32), ("FrameCount", C.c_uint32), ("DebugDataMaxValues", C.c_int32 * 2),
+                ("SceneObjectReservoirTestsNum", C.c_uint32), ("TriReservoirTestsNum", C.c_uint32),
+                ("ReuseBufferCycle", C.c_int32), ("MaxOffset", C.c_int32), ("TemporalCandidatesNum", C.c_uint32),
+                ("SpatialHitPointDiffThreshold", C.c_float), ("SpatialNormalsAngleThreshold", C.c_float),
+                ("SpatialBRDFThreshold", C.c_float), ("TemporalReuseWeight", C.c_float),
+                ("PixelMovementThreshold", C.c_float), ("TemporalPrecisionThreshold", C.c_float),
+                ("EmittingObjectsNum", C.c_uint32), ("TextureAtlasDimsRaw", C.c_uint32 * 2),
+                ("EnvironmentMapTexDimsRaw", C.c_uint32 * 2), ("kw_VIS_REUSE", C.c_int32),
+                ("kw_WEIGHT_RECALC", C.c_int32), ("kw_BRDF", C.c_int32), ("row0", C.c_int32), ("row1", C.c_int32)]
+
+
+class OrcScene(C.Structure):
+    _fields_ = [("BVs", C.c_void_p), ("nBVs", C.c_int64), ("SceneObjects", C.c_void_p), ("nSceneObjects", C.c_int64),
+                ("LightObjects", C.c_void_p), ("nLightObjects", C.c_int64), ("Materials", C.c_void_p),
+                ("nMaterials", C.c_int64), ("Triangles", C.c_void_p), ("nTriangles", C.c_int64),
+                ("Vertices", C.c_void_p), ("nVertices", C.c_int64), ("TextureAtlas", C.c_void_p),
+                ("atlasW", C.c_int32), ("atlasH", C.c_int32), ("EnvironmentMap", C.c_void_p), ("envW", C.c_int32),
+                ("envH", C.c_int32)]
+
+
+class OrcCounters(C.Structure):
+    _fields_ = [(n, C.c_uint64) for n in ("rays", "pops", "bvChecks", "objVisits", "triIters", "triChecks",
+                                          "validNeighbours", "activePixels")]
+
+    def as_dict(self):
+        return {n: int(getattr(self, n)) for n, _ in self._fields_}
+
+
+class OrcFrame(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("HitInfos", "Candidates", "CandidatesB", "TemporalFrameBuffer", "Result",
+                                          "AccumulatedResult", "DebugOverlay", "DepthBuffer", "NormalsBuffer",
+                                          "RayHitPointsA", "RayHitPointsB", "records", "counters")]
+
+
+_oracle = None
+
+
+def oracle_lib():
+    global _oracle
+    if _oracle is None:
+        path = os.path.join(ROOT, "oracle", "librtoracle.so")
+        if not os.path.exists(path):
+            raise RuntimeError(f"{path} missing: run `make oracle`")
+        lib = C.CDLL(path)
+        ps, pp, pf, ci = C.POINTER(OrcScene), C.POINTER(OrcParams), C.POINTER(OrcFrame), C.c_int
+        for name in ("orc_initial_trace", "orc_temporal_reuse", "orc_spatial_reuse_pass", "orc_transfer_to_original",
+                     "orc_trace_rays"):
+            getattr(lib, name).restype, getattr(lib, name).argtypes = ci, [ps, pp, pf, ci]
+        lib.orc_calc_tri_normals.restype, lib.orc_calc_tri_normals.argtypes = ci, [ps, ci]
+        lib.orc_accumulate_frames.restype, lib.orc_accumulate_frames.argtypes = ci, [pp, pf, ci, ci]
+        u32p, fp = C.POINTER(C.c_uint32), C.POINTER(C.c_float)
+        lib.orc_next_random.restype, lib.orc_next_random.argtypes = C.c_uint32, [u32p]
+        lib.orc_rand_normalized.restype, lib.orc_rand_normalized.argtypes = C.c_float, [u32p]
+        lib.orc_rand_int_span.restype, lib.orc_rand_int_span.argtypes = C.c_int32, [C.c_int32, C.c_int32, u32p]
+        lib.orc_weighted_rand.restype, lib.orc_weighted_rand.argtypes = C.c_int32, [C.c_float, C.c_float, u32p]
+        lib.orc_ray_bv_intersect.restype, lib.orc_ray_bv_intersect.argtypes = C.c_float, [fp, fp, C.c_void_p]
+        lib.orc_ray_triangle_intersect.restype = C.c_int32
+        lib.orc_ray_triangle_intersect.argtypes = [fp, fp, C.c_void_p, C.c_void_p, C.c_void_p, fp, fp]
+        lib.orc_get_brdf.restype, lib.orc_get_brdf.argtypes = C.c_float, [fp, fp, fp, C.c_float, C.c_float]
+        lib.orc_detmath1.restype, lib.orc_detmath1.argtypes = C.c_float, [ci, C.c_float]
+        lib.orc_detmath2.restype, lib.orc_detmath2.argtypes = C.c_float, [ci, C.c_float, C.c_float]
+        lib.orc_num_threads.restype = ci
+        _oracle = lib
+    return _oracle
+
+
+def mat3_rowmajor_from_colmajor4(m16):
+    m = np.asarray(m16, dtype=np.float32).reshape(4, 4).T  # m[r][c]
+    return np.ascontiguousarray(m[:3, :3]).reshape(9)
+
+
+class OracleRenderer:
+    """The reference's frame loop on the CPU oracle.  Buffers are numpy arrays in the ABI (array-of-structures)
+    layout; render targets are (H, W, 4) float32 arrays, the depth buffer (H, W)."""
+
+    def __init__(self, scene_arrays, cfg, threads=0, records=True, row0=0, row1=0):
+        self.lib = oracle_lib()
+        self.cfg = cfg
+        self.threads = threads
+        self.a = {k: (v.copy() if isinstance(v, np.ndarray) else v) for k, v in scene_arrays.items()}
+        W, H = cfg.Resolution[0], cfg.Resolution[1]
+        self.W, self.H = W, H
+        n = W * H
+        self.buf = {
+            "HitInfos": np.zeros(n, DT["HitInfo"]), "Candidates": np.zeros(n, DT["Reservoir"]),
+            "CandidatesB": np.zeros(n, DT["Reservoir"]), "TemporalFrameBuffer": np.zeros(n, DT["Reservoir"]),
+        }
+        self.tex = {k: np.zeros((H, W, 4), np.float32) for k in ("Result", "AccumulatedResult", "DebugOverlay",
+                                                                  "NormalsBuffer", "RayHitPointsA", "RayHitPointsB")}
+        self.tex["DepthBuffer"] = np.zeros((H, W), np.float32)
+        self.records = np.zeros(n, DT["TraceRecord"]) if records else None
+        self.atlas = np.zeros((1, 1, 4), np.float32)
+        self.env = np.array([[[0.5, 0.7, 1.0, 1.0]]], np.float32)
+        self.counters = OrcCounters()
+        self.FrameCount = 0
+        self.frames_started = 0
+        self.p = OrcParams()
+        self._static_params(row0, row1)
+        s = OrcScene()
+        a = self.a
+        s.BVs, s.nBVs = a["BVs"].ctypes.data, len(a["BVs"])
+        s.SceneObjects, s.nSceneObjects = a["SceneObjects"].ctypes.data, len(a["SceneObjects"])
+        s.LightObjects, s.nLightObjects = a["LightObjects"].ctypes.data, len(a["LightObjects"])
+        s.Materials, s.nMaterials = a["Materials"].ctypes.data, len(a["Materials"])
+        s.Triangles, s.nTriangles = a["Triangles"].ctypes.data, len(a["Triangles"])
+        s.Vertices, s.nVertices = a["Vertices"].ctypes.data, len(a["Vertices"])
+        s.TextureAtlas, s.atlasW, s.atlasH = self.atlas.ctypes.data, 1, 1
+        s.EnvironmentMap, s.envW, s.envH = self.env.ctypes.data, 1, 1
+        self.s = s
+        f = OrcFrame()
+        for k in ("HitInfos", "Candidates", "CandidatesB", "TemporalFrameBuffer"):
+            setattr(f, k, self.buf[k].ctypes.data)
+        for k, v in self.tex.items():
+            setattr(f, k, v.ctypes.data)
+        f.records = self.records.ctypes.data if records else None
+        f.counters = C.addressof(self.counters)
+        self.f = f
+        self.lib.orc_calc_tri_normals(C.byref(self.s), threads)  # RunPreCalcShader, Main.cs:294
+
+    def _static_params(self, row0, row1):
+        p, cfg, a = self.p, self.cfg, self.a
+        host = rt.host_lib()
+        p.TrianglesNum, p.BVsNum = len(a["Triangles"]), len(a["BVs"])
+        p.MaxBVHDepth, p.SceneBVHStartIndex = a["maxBVHDepth"], a["sceneBVHStartIndex"]
+        p.SceneObjectsNum, p.EmittingObjectsNum = len(a["SceneObjects"]), a["emittingObjectsNum"]
+        p.ScatterProbability, p.MaxBounceCount = cfg.ScatterProbability, cfg.MaxBounceCount
+        p.Resolution[0], p.Resolution[1] = cfg.Resolution[0], cfg.Resolution[1]
+        vsd = (C.c_float * 2)()
+        host.rth_view_space_dims(cfg.fieldOfView, cfg.Resolution[0], cfg.Resolution[1], vsd)
+        p.ViewSpaceDims[0], p.ViewSpaceDims[1] = vsd[0], vsd[1]
+        p.DefocusStrength, p.FocalPlaneFactor = cfg.DefocusStrength, cfg.FocalPlaneFactor
+        t, ti = (C.c_float * 16)(), (C.c_float * 16)()
+        host.rth_camera_matrices(cfg.cameraPosition, cfg.cameraRotation, t, ti)
+        ct = mat3_rowmajor_from_colmajor4(list(t))
+        cti = mat3_rowmajor_from_colmajor4(list(ti))
+        for i in range(3):
+            p.WorldSpaceCameraPos[i] = cfg.cameraPosition[i]
+            p.LastWorldSpaceCameraPos[i] = cfg.cameraPosition[i]
+        for i in range(9):
+            p.CameraTransform[i] = float(ct[i])
+            p.LastCameraTransformInverse[i] = float(cti[i])
+        p.DebugDataMaxValues[0], p.DebugDataMaxValues[1] = cfg.DebugMaxTriChecks, cfg.DebugMaxBVChecks
+        p.SceneObjectReservoirTestsNum, p.TriReservoirTestsNum = cfg.SceneObjectReservoirTestsNum, cfg.TriReservoirTestsNum
+        p.TemporalCandidatesNum = cfg.TemporalCandidatesNum
+        p.SpatialHitPointDiffThreshold = cfg.SpatialHitPointDiffThreshold
+        p.SpatialNormalsAngleThreshold = cfg.SpatialNormalsAngleThreshold
+        p.SpatialBRDFThreshold = cfg.SpatialBRDFThreshold
+        p.TemporalReuseWeight, p.PixelMovementThreshold = cfg.TemporalReuseWeight, cfg.PixelMovementThreshold
+        p.TemporalPrecisionThreshold = cfg.TemporalPrecisionThreshold
+        p.TextureAtlasDimsRaw[0] = p.TextureAtlasDimsRaw[1] = 1      # SetInts("TextureAtlasDims", {1, 1})
+        p.EnvironmentMapTexDimsRaw[0] = p.EnvironmentMapTexDimsRaw[1] = 1
+        p.kw_VIS_REUSE, p.kw_WEIGHT_RECALC, p.kw_BRDF = cfg.DoVisibilityReuse, cfg.DoWeightRecalc, cfg.DoBRDF
+        p.row0, p.row1 = row0, row1
+
+    def set_band(self, row0, row1):
+        self.p.row0, self.p.row1 = row0, row1
+
+    # ---- Main.cs sequence ----
+    def update_per_frame(self):
+        cfg = self.cfg
+        self.p.FrameRand = (cfg.frameRandBase + cfg.frameRandStep * self.frames_started) % 999999
+        self.frames_started += 1
+        self.p.FrameCount = self.FrameCount
+        self.pp_frame_count = self.FrameCount
+        self.FrameCount += 1
+
+    def _run(self, fn):
+        rc = fn(C.byref(self.s), C.byref(self.p), C.byref(self.f), self.threads)
+        assert rc == 0
+
+    def initial_trace(self):
+        self._run(self.lib.orc_initial_trace)
+
+    def temporal_reuse(self):
+        if self.cfg.TemporalReuseWeight > 0:
+            self._run(self.lib.orc_temporal_reuse)
+
+    def spatial_pass(self, i, cycle):
+        self.p.MaxOffset = int(np.float32(3.0 ** i)) * self.cfg.SpatialReuseBlur
+        self.p.ReuseBufferCycle = 1 if cycle else 0
+        self._run(self.lib.orc_spatial_reuse_pass)
+
+    def transfer_to_original(self):
+        self._run(self.lib.orc_transfer_to_original)
+
+    def spatial_reuse(self):
+        cycle = False
+        for i in range(self.cfg.SpatialReuseIterations):
+            cycle = not cycle
+            self.spatial_pass(i, cycle)
+        if cycle:
+            self.transfer_to_original()
+
+    def trace_rays(self):
+        self._run(self.lib.orc_trace_rays)
+
+    def accumulate(self):
+        rc = self.lib.orc_accumulate_frames(C.byref(self.p), C.byref(self.f), self.pp_frame_count, self.threads)
+        assert rc == 0
+
+    def run_stage(self, stage):
+        [self.initial_trace, self.temporal_reuse, self.spatial_reuse, self.trace_rays][stage]()
+
+    def render_frame(self):
+        self.update_per_frame()
+        self.initial_trace()
+        self.temporal_reuse()
+        if self.cfg.SpatialReuseIterations > 0:
+            self.spatial_reuse()
+        self.trace_rays()
+        self.accumulate()
+
+    def take_counters(self):
+        d = self.counters.as_dict()
+        C.memset(C.addressof(self.counters), 0, C.sizeof(self.counters))
+        return d
+
+
+def small_config(w=64, h=64):
+    cfg = rt.default_config()
+    cfg.Resolution[0], cfg.Resolution[1] = w, h
+    return cfg
+
+
+def bits(a):
+    """Raw bytes of a (structured) array, for bit-exact comparison that treats NaNs and signed zeros literally."""
+    return np.ascontiguousarray(a).view(np.uint8).reshape(-1)
