@@ -1,0 +1,199 @@
+#!/usr/bin/env python3
+"""Benchmark of the ReSTIR direct-lighting frame on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+
+One step = one frame of the reference's sequence (InitialTrace, TemporalReuse, 3 x SpatialReusePass,
+TransferToOriginal, TraceRays, AccumulateFrames) on the "80kScene*" stand-in at 1920x1080, all inputs resident in
+HBM before the timed region.  N > 1 splits the same image into N row bands, one process per GPU (launched by
+torch.distributed.run), with reservoir halos exchanged between neighbours before every spatial pass and the frame
+buffer gathered on rank 0 (strong scaling).  Rank 0 prints ONE JSON line.
+
+value = rays cast by all ranks in the K timed frames / wall time of those frames, in Mrays/s (primary + shadow +
+light rays, counted by the kernels themselves).
+"""
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak
+
+
+def algorithmic_bytes(kernel, c, npx_launch):
+    """Algorithmic bytes of ONE launch from its work counters `c` (per-launch averages).
+
+    Traversal kernels: 32 B per node popped and per child box fetched, 168 B per scene-object visit, 28 B per
+    leaf-loop triangle, 60 B (three vertices) per triangle tested — the reference's access pattern — plus the
+    per-pixel records the kernel streams.  Reuse passes: their per-pixel record traffic.
+    """
+    trav = 32 * (c["pops"] + c["bvChecks"]) + 168 * c["objVisits"] + 28 * c["triIters"] + 60 * c["triChecks"]
+    px = c["activePixels"]
+    if kernel == "primary":
+        return trav + px * (52 + 16 + 4 + 16 + 16)          # HitInfo, DebugOverlay, depth, normals, hit point
+    if kernel == "candidates":
+        return trav + npx_launch * 52 + c["rays"] * 52      # HitInfo read per pixel, reservoir write per candidate
+    if kernel == "trace_rays":
+        return trav + px * (52 + 52 + 16)
+    if kernel == "temporal":
+        return px * (52 + 52 + 4 + 16 + 16 + 52 + 52)
+    if kernel == "spatial":
+        return px * (4 + 52 + 52) + c["validNeighbours"] * (4 + 52)
+    if kernel == "transfer":
+        return px * (4 + 52 + 52)
+    if kernel == "accumulate":
+        return npx_launch * 48
+    return 0
+
+
+def cpu_baseline(rt, scene, cfg, frames, threads):
+    """The CPU oracle (a port of the reference's kernels) on the same scene, resolution and constants."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import harness as h
+    orc = h.OracleRenderer(scene.arrays(), cfg, threads=threads, records=False)
+    orc.render_frame()  # frame 0 (no temporal history yet): untimed warm-up
+    orc.take_counters()
+    t0 = time.perf_counter()
+    for _ in range(frames):
+        orc.render_frame()
+    dt = time.perf_counter() - t0
+    c = orc.take_counters()
+    return {"value": c["rays"] / 1e6 / dt, "unit": "Mrays/s", "cores": threads, "kind": "port",
+            "sample": f"{frames} full ReSTIR frame(s) (frame index 1..{frames}) of the same 1920x1080 workload, "
+                      f"{dt / frames * 1e3:.0f} ms/frame on {threads} threads",
+            "ms_per_frame": dt / frames * 1e3}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=64)
+    ap.add_argument("--warmup", type=int, default=8)
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-frames", type=int, default=2)
+    ap.add_argument("--small-scene", action="store_true", help="8.7k-triangle dragon instead of the 78k stand-in")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus N > 1 must be launched with torch.distributed.run (one process per GPU)")
+        args.gpus = world
+
+    rt = importlib.import_module("ray-tracer_amd")
+    scene = rt.build_scene_s0(subdivide=not args.small_scene)
+    cfg = rt.default_config()
+    cfg.Resolution[0], cfg.Resolution[1] = args.width, args.height
+    W, H = args.width, args.height
+
+    if world > 1:
+        mg = importlib.import_module("ray-tracer_amd.multigpu")
+        runner = mg.DistributedRunner(rt, scene, cfg, rank, world, local_rank)
+    else:
+        runner = SingleRunner(rt, scene, cfg)
+
+    ctx = runner.ctx
+    ctx.enable_stats(1)
+    for _ in range(args.warmup):
+        runner.render_frame()
+    runner.sync()
+    ctx.profile_reset()
+    ctx.profile_enable(True)
+    runner.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        runner.render_frame()
+    runner.sync()
+    runner.barrier()
+    dt = time.perf_counter() - t0
+    ctx.profile_enable(False)
+    prof = ctx.profile()
+    rays_local = sum(k["rays"] for k in prof.values())
+    dt_max, rays_total = runner.reduce(dt, rays_local)
+
+    # Work counters for the roofline: a few more frames with the instrumented kernels, untimed.
+    ctx.profile_reset()
+    ctx.enable_stats(2)
+    n_instr = 4
+    for _ in range(n_instr):
+        runner.render_frame()
+    runner.sync()
+    iprof = ctx.profile()
+    ctx.enable_stats(0)
+
+    if rank == 0:
+        band_px = runner.band_pixels()
+        kernels = {}
+        for name, p in prof.items():
+            ms = p["ms"] / max(1, p["launches"])
+            entry = {"launches_per_frame": p["launches"] / args.steps, "avg_ms": ms}
+            if name in iprof:
+                c = {k: v / iprof[name]["launches"] for k, v in iprof[name].items() if k not in ("launches", "ms")}
+                b = algorithmic_bytes(name, c, band_px)
+                entry["algorithmic_MB_per_launch"] = b / 1e6
+                entry["achieved_GBs"] = b / 1e9 / (ms / 1e3) if ms > 0 else None
+            kernels[name] = entry
+        timed = {k: v for k, v in kernels.items() if v.get("achieved_GBs")}
+        dominant = max(timed, key=lambda k: timed[k]["avg_ms"] * timed[k]["launches_per_frame"]) if timed else None
+        roofline = None
+        if dominant:
+            d = timed[dominant]
+            roofline = {"bound": "hbm", "kernel": dominant, "achieved": d["achieved_GBs"], "peak": HBM_PEAK_GBS,
+                        "unit": "GB/s", "frac": d["achieved_GBs"] / HBM_PEAK_GBS, "traffic": None,
+                        "avg_launch_ms": d["avg_ms"], "algorithmic_MB_per_launch": d["algorithmic_MB_per_launch"]}
+        out = {
+            "metric": "Mrays/s (primary+shadow) ReSTIR DL, 80kScene 1080p",
+            "value": rays_total / 1e6 / dt_max, "unit": "Mrays/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": dt_max / args.steps * 1e3, "higher_is_better": True,
+            "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"BVH_ReSTIR_DL 80kScene* ({'8.7k' if args.small_scene else '78k'}-triangle dragon stand-in "
+                                   f"+ Suzanne light) {W}x{H}, temporal + 3 spatial reuse passes, VIS_REUSE+BRDF",
+                       "resolution": [W, H], "triangles": int(len(scene.arrays()['Triangles'])),
+                       "parallelism": f"row-bands x{world}" if world > 1 else "single GPU",
+                       "rays_per_frame": rays_total / args.steps},
+            "roofline": roofline, "kernels": kernels,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            threads = min(16, os.cpu_count() or 1)
+            out["cpu_baseline"] = cpu_baseline(rt, scene, cfg, args.cpu_frames, threads)
+        print(json.dumps(out))
+    runner.close()
+
+
+class SingleRunner:
+    def __init__(self, rt, scene, cfg):
+        self.ctx = rt.RtContext(0)
+        self.drv = rt.Driver(self.ctx, cfg, scene)
+        self.npx = cfg.Resolution[0] * cfg.Resolution[1]
+
+    def render_frame(self):
+        self.drv.render_frame()
+
+    def sync(self):
+        self.ctx.sync()
+
+    def barrier(self):
+        pass
+
+    def reduce(self, dt, rays):
+        return dt, rays
+
+    def band_pixels(self):
+        return self.npx
+
+    def close(self):
+        self.drv.close()
+        self.ctx.close()
+
+
+if __name__ == "__main__":
+    main()

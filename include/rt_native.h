@@ -150,6 +150,20 @@ typedef struct {
 int rt_enable_stats(rt_ctx ctx, int level);
 int rt_get_stats(rt_shader sh, int kernel, rt_dispatch_stats* out);
 
+/* Per-kernel profile.  One dispatch may run several GPU kernels; they are named "primary", "candidates" (the two
+ * halves of InitialTrace), "temporal", "spatial", "transfer", "trace_rays", "accumulate", "calc_tri_normals".
+ * With timing enabled every launch is bracketed by HIP events on the context's stream.  rt_profile_get waits for
+ * enqueued work and returns launches, summed milliseconds and summed counters since the last rt_profile_reset
+ * (it does not reset; rt_get_stats and rt_profile_reset do). */
+typedef struct {
+    uint64_t launches;
+    double milliseconds;
+    rt_dispatch_stats stats;
+} rt_kernel_profile;
+int rt_profile_enable(rt_ctx ctx, int timing);
+int rt_profile_reset(rt_ctx ctx);
+int rt_profile_get(rt_ctx ctx, const char* kernel_name, rt_kernel_profile* out);
+
 #ifdef __cplusplus
 }
 #endif

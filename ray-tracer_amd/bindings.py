@@ -70,6 +70,7 @@ def native_lib():
             "rt_texture_set_data": (ci, [vp, vp, C.c_size_t]), "rt_texture_get_data": (ci, [vp, vp, C.c_size_t]),
             "rt_texture_release": (None, [vp]),
             "rt_enable_stats": (ci, [vp, ci]), "rt_get_stats": (ci, [vp, ci, vp]),
+            "rt_profile_enable": (ci, [vp, ci]), "rt_profile_reset": (ci, [vp]), "rt_profile_get": (ci, [vp, cs, vp]),
         }
         for name, (res, args) in sig.items():
             fn = getattr(lib, name)
@@ -114,6 +115,13 @@ class DispatchStats(C.Structure):
 
     def as_dict(self):
         return {n: int(getattr(self, n)) for n, _ in self._fields_}
+
+
+class KernelProfile(C.Structure):
+    _fields_ = [("launches", C.c_uint64), ("milliseconds", C.c_double), ("stats", DispatchStats)]
+
+
+KERNEL_NAMES = ("primary", "candidates", "temporal", "spatial", "transfer", "trace_rays", "accumulate", "calc_tri_normals")
 
 
 def host_lib():
@@ -332,6 +340,22 @@ class RtContext:
         s = DispatchStats()
         self.check(self.lib.rt_get_stats(shader, kernel, C.byref(s)), "rt_get_stats")
         return s.as_dict()
+
+    def profile_enable(self, timing):
+        self.check(self.lib.rt_profile_enable(self.h, 1 if timing else 0), "rt_profile_enable")
+
+    def profile_reset(self):
+        self.check(self.lib.rt_profile_reset(self.h), "rt_profile_reset")
+
+    def profile(self):
+        """{kernel name: {"launches", "ms", counters...}} for every internal kernel launched since the last reset."""
+        out = {}
+        for name in KERNEL_NAMES:
+            p = KernelProfile()
+            self.check(self.lib.rt_profile_get(self.h, name.encode(), C.byref(p)), "rt_profile_get")
+            if p.launches:
+                out[name] = {"launches": int(p.launches), "ms": float(p.milliseconds), **p.stats.as_dict()}
+        return out
 
     def close(self):
         if self.h:

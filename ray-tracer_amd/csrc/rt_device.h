@@ -92,6 +92,7 @@ struct KParams {
     int32_t ppFrameCount;
     // band + instrumentation
     int32_t row0, row1;
+    const uint32_t* blockMap;  // launch block index -> (by << 16 | bx) of the 16x16-pixel block it renders, ~0u = none
     unsigned long long* stats;  // 8 counters (rt_dispatch_stats order) or null
     uint32_t* records;          // 8 dwords per pixel (trace record) or null
 };

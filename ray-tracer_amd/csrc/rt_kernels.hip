@@ -178,25 +178,19 @@ DEV v3 matCol(const KParams& P, const rt_material& m, v2 uv) {
 }
 
 // ---------------- thread -> pixel mapping ----------------
-// One wave per 8x8 tile.  Workgroup b of the launch runs on XCD (b mod 8) (observed round-robin placement, used
-// for L2 locality only); remap so each XCD gets a contiguous run of workgroups, i.e. a compact image region.
-DEV uint32_t xcdRemap(uint32_t b, uint32_t n) {
-    uint32_t q = n / 8, r = n % 8, xcd = b % 8, k = b / 8;
-    uint32_t base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
-    return base + k;
-}
+// One wave per 8x8 tile, four waves (a 16x16-pixel block) per workgroup.  Which block a workgroup renders comes
+// from a table built on the host (rt_native.hip: buildBlockMap), which orders blocks so that the workgroups that
+// land on one XCD (launch index mod 8, the observed round-robin placement; used for speed only) render compact
+// image regions, and the regions are dealt evenly to the XCDs.
 struct Pixel { int x, y; bool active; };
 DEV Pixel pixelOfThread(const KParams& P) {
-    // workgroups tile the band as 2x2 groups of 8x8 tiles (16x16 pixels)
-    int bandY0 = P.row0 & ~7;
-    uint32_t gx = (uint32_t)(P.ResX + 15) / 16;
-    uint32_t b = xcdRemap(blockIdx.x, gridDim.x);
-    uint32_t by = b / gx, bx = b % gx;
-    uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const uint32_t m = P.blockMap[blockIdx.x];
+    const uint32_t bx = m & 0xffffu, by = m >> 16;
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     Pixel p;
     p.x = (int)(bx * 16 + (wave & 1) * 8 + (lane & 7));
-    p.y = bandY0 + (int)(by * 16 + (wave >> 1) * 8 + (lane >> 3));
-    p.active = p.x < P.ResX && p.y < P.ResY && p.y >= P.row0 && p.y < P.row1;
+    p.y = (P.row0 & ~7) + (int)(by * 16 + (wave >> 1) * 8 + (lane >> 3));
+    p.active = m != 0xffffffffu && p.x < P.ResX && p.y < P.ResY && p.y >= P.row0 && p.y < P.row1;
     return p;
 }
 

@@ -8,6 +8,7 @@
 
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <string>
@@ -21,6 +22,9 @@ namespace {
 
 enum ShaderKind { SH_RESTIR = 0, SH_RIS = 1, SH_PRECALC = 2, SH_POSTPROC = 3 };
 enum BufLayout { LAYOUT_AOS = 0, LAYOUT_RESERVOIR_PLANES = 1, LAYOUT_HIT_PLANES = 2 };
+// the kernels a dispatch is made of (one ABI dispatch may launch several)
+enum InternalKernel { IK_PRIMARY = 0, IK_CANDIDATES, IK_TEMPORAL, IK_SPATIAL, IK_TRANSFER, IK_TRACE_RAYS, IK_ACCUMULATE, IK_CALC_NORMALS, IK_COUNT };
+const char* const IK_NAMES[IK_COUNT] = {"primary", "candidates", "temporal", "spatial", "transfer", "trace_rays", "accumulate", "calc_tri_normals"};
 
 }  // namespace
 
@@ -30,6 +34,19 @@ struct rt_ctx_s {
     std::string err;
     int row0 = 0, row1 = 0;
     int statsLevel = 0;  // 0 off, 1 rays + active pixels, 2 all counters (instrumented kernel variants)
+    unsigned long long* statsDev = nullptr;  // IK_COUNT x 8 counters, accumulated until read
+    // workgroup -> image block table of the per-pixel kernels (see buildBlockMap)
+    uint32_t* blockMapDev = nullptr;
+    size_t blockMapCap = 0;
+    unsigned blockMapN = 0;
+    int bmBx = -1, bmBy = -1, bmMode = -1;
+    // per-internal-kernel timing with HIP events on the context's stream
+    bool timing = false;
+    struct Timed { int kernel; hipEvent_t start, stop; };
+    std::vector<Timed> pending;
+    std::vector<hipEvent_t> freeEvents;
+    double timeMs[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    uint64_t launches[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     uint64_t versionCounter = 1;
     // prepared traversal data (derived from the bound scene buffers)
     struct Prep {
@@ -70,7 +87,6 @@ struct rt_shader_s {
     std::map<std::string, rt_buffer> buffers[8];
     std::map<std::string, rt_texture> textures[8];
     bool kwVisReuse = false, kwWeightRecalc = false, kwBrdf = false;
-    unsigned long long* statsDev = nullptr;  // 8 kernels x 8 counters, accumulated until read by rt_get_stats
 };
 
 namespace {
@@ -346,6 +362,50 @@ void fillConstants(rt_shader sh, KParams& P) {
     P.ppFrameCount = (int32_t)cWord(sh, "FrameCount");
 }
 
+// Order in which workgroups render the bx x by grid of 16x16-pixel blocks.  Workgroup i of a launch runs on XCD
+// i mod 8 and workgroups start in index order, so the table is built as 8 per-XCD lists interleaved: each XCD
+// walks compact regions of the image (its L2 keeps seeing the same part of the BVH), regions are dealt to the
+// XCDs cyclically (cost varies a lot over the image, so contiguous eighths would leave most XCDs idle), and at any
+// moment the 8 XCDs work on neighbouring regions of similar cost.
+// mode 0: plain row-major order; 1: one contiguous eighth of the image per XCD; 2 (default): cyclic regions.
+std::vector<uint32_t> buildBlockMap(unsigned bx, unsigned by, int mode) {
+    std::vector<uint32_t> rowMajor;
+    for (unsigned y = 0; y < by; y++) for (unsigned x = 0; x < bx; x++) rowMajor.push_back(y << 16 | x);
+    if (mode == 0) return rowMajor;
+    std::vector<std::vector<uint32_t>> lists(8);
+    if (mode == 1) {
+        size_t n = rowMajor.size(), q = n / 8, r = n % 8, pos = 0;
+        for (unsigned x = 0; x < 8; x++) {
+            size_t len = q + (x < r ? 1 : 0);
+            lists[x].assign(rowMajor.begin() + pos, rowMajor.begin() + pos + len);
+            pos += len;
+        }
+    } else {
+        const unsigned RW = 4, RH = 4;  // region = 4x4 blocks = 64x64 pixels
+        unsigned rx = (bx + RW - 1) / RW, ry = (by + RH - 1) / RH, region = 0;
+        for (unsigned j = 0; j < ry; j++)
+            for (unsigned i = 0; i < rx; i++, region++) {
+                // shift the cyclic assignment by row so vertically adjacent regions go to different XCDs too
+                std::vector<uint32_t>& l = lists[(region + 3 * j) % 8];
+                for (unsigned y = j * RH; y < (j + 1) * RH && y < by; y++)
+                    for (unsigned x = i * RW; x < (i + 1) * RW && x < bx; x++) l.push_back(y << 16 | x);
+            }
+    }
+    size_t longest = 0;
+    for (auto& l : lists) longest = l.size() > longest ? l.size() : longest;
+    std::vector<uint32_t> out;
+    out.reserve(longest * 8);
+    for (size_t k = 0; k < longest; k++)
+        for (unsigned x = 0; x < 8; x++) out.push_back(k < lists[x].size() ? lists[x][k] : 0xffffffffu);
+    while (out.size() >= 8) {  // drop trailing rounds that are all padding
+        bool allPad = true;
+        for (size_t i = out.size() - 8; i < out.size(); i++) allPad = allPad && out[i] == 0xffffffffu;
+        if (!allPad) break;
+        out.resize(out.size() - 8);
+    }
+    return out;
+}
+
 // Launch geometry of the per-pixel kernels: 256-thread workgroups, each a 2x2 group of 8x8 tiles, covering the
 // context's row band (whole image by default).  The caller's group counts only have to cover the image.
 int pixelGrid(rt_ctx ctx, KParams& P, int gx, int gy, unsigned* blocks) {
@@ -357,12 +417,63 @@ int pixelGrid(rt_ctx ctx, KParams& P, int gx, int gy, unsigned* blocks) {
     if (P.row1 <= P.row0) { *blocks = 0; return RT_OK; }
     int bandY0 = P.row0 & ~7;
     unsigned bx = (unsigned)(P.ResX + 15) / 16, by = (unsigned)(P.row1 - bandY0 + 15) / 16;
-    *blocks = bx * by;
+    if (bx > 0xffffu || by > 0xffffu) return fail(ctx, RT_ERR_LIMIT, "image too large for the block table");
+    static const int mode = [] { const char* e = getenv("RT_BLOCK_MAP"); return e ? atoi(e) : 2; }();
+    if ((int)bx != ctx->bmBx || (int)by != ctx->bmBy || mode != ctx->bmMode) {
+        std::vector<uint32_t> map = buildBlockMap(bx, by, mode);
+        if (map.size() > ctx->blockMapCap) {
+            HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+            if (ctx->blockMapDev) { hipError_t e = hipFree(ctx->blockMapDev); (void)e; ctx->blockMapDev = nullptr; ctx->blockMapCap = 0; }
+            HIP_TRY(ctx, hipMalloc((void**)&ctx->blockMapDev, map.size() * 4));
+            ctx->blockMapCap = map.size();
+        }
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));  // earlier launches may still read the old table
+        HIP_TRY(ctx, hipMemcpy(ctx->blockMapDev, map.data(), map.size() * 4, hipMemcpyHostToDevice));
+        ctx->blockMapN = (unsigned)map.size();
+        ctx->bmBx = (int)bx; ctx->bmBy = (int)by; ctx->bmMode = mode;
+    }
+    P.blockMap = ctx->blockMapDev;
+    *blocks = ctx->blockMapN;
     return RT_OK;
 }
 
-void beginStats(rt_shader sh, int kernel, KParams& P) {
-    P.stats = (sh->ctx->statsLevel > 0 && sh->statsDev) ? sh->statsDev + kernel * 8 : nullptr;
+// Launch bracket: points the kernel at its counter slot and, when timing is on, records events around it.
+struct LaunchScope {
+    rt_ctx ctx;
+    int ik;
+    hipEvent_t start = nullptr, stop = nullptr;
+    LaunchScope(rt_ctx c, int k, KParams* P) : ctx(c), ik(k) {
+        if (P) P->stats = ctx->statsLevel > 0 ? ctx->statsDev + k * 8 : nullptr;
+        ctx->launches[k]++;
+        if (!ctx->timing) return;
+        auto take = [&]() -> hipEvent_t {
+            if (!ctx->freeEvents.empty()) { hipEvent_t e = ctx->freeEvents.back(); ctx->freeEvents.pop_back(); return e; }
+            hipEvent_t e = nullptr;
+            if (hipEventCreate(&e) != hipSuccess) return nullptr;
+            return e;
+        };
+        start = take();
+        stop = take();
+        if (start && stop) { hipError_t e = hipEventRecord(start, ctx->stream); (void)e; }
+    }
+    ~LaunchScope() {
+        if (!start || !stop) return;
+        hipError_t e = hipEventRecord(stop, ctx->stream);
+        (void)e;
+        ctx->pending.push_back({ik, start, stop});
+    }
+};
+int drainTiming(rt_ctx ctx) {
+    if (ctx->pending.empty()) return RT_OK;
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    for (auto& t : ctx->pending) {
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, t.start, t.stop) == hipSuccess) ctx->timeMs[t.kernel] += ms;
+        ctx->freeEvents.push_back(t.start);
+        ctx->freeEvents.push_back(t.stop);
+    }
+    ctx->pending.clear();
+    return RT_OK;
 }
 
 int dispatchReSTIR(rt_shader sh, int kernel, int gx, int gy) {
@@ -387,7 +498,7 @@ int dispatchReSTIR(rt_shader sh, int kernel, int gx, int gy) {
         instr = true;
     }
     if (ctx->statsLevel >= 2) instr = true;
-    beginStats(sh, kernel, P);
+    if (ctx->timing && ctx->pending.size() > 8192 && (rc = drainTiming(ctx))) return rc;
     switch (kernel) {
         case 0: {  // InitialTrace
             if ((rc = prepareScene(sh, kernel, P))) return rc;
@@ -405,12 +516,15 @@ int dispatchReSTIR(rt_shader sh, int kernel, int gx, int gy) {
             optionalTex(sh, kernel, "TextureAtlas", P.atlas);
             if (!blocks) break;
             size_t ldsBytes = (size_t)WAVES_PER_BLOCK * P.stackDepth * 64 * 4;
-            if (instr) {
-                hipLaunchKernelGGL(k_primary<true>, dim3(blocks), dim3(256), ldsBytes, ctx->stream, P);
-                hipLaunchKernelGGL(k_candidates<true>, dim3(blocks), dim3(256), ldsBytes, ctx->stream, P);
-            } else {
-                hipLaunchKernelGGL(k_primary<false>, dim3(blocks), dim3(256), ldsBytes, ctx->stream, P);
-                hipLaunchKernelGGL(k_candidates<false>, dim3(blocks), dim3(256), ldsBytes, ctx->stream, P);
+            {
+                LaunchScope ls(ctx, IK_PRIMARY, &P);
+                if (instr) hipLaunchKernelGGL(k_primary<true>, dim3(blocks), dim3(256), ldsBytes, ctx->stream, P);
+                else hipLaunchKernelGGL(k_primary<false>, dim3(blocks), dim3(256), ldsBytes, ctx->stream, P);
+            }
+            {
+                LaunchScope ls(ctx, IK_CANDIDATES, &P);
+                if (instr) hipLaunchKernelGGL(k_candidates<true>, dim3(blocks), dim3(256), ldsBytes, ctx->stream, P);
+                else hipLaunchKernelGGL(k_candidates<false>, dim3(blocks), dim3(256), ldsBytes, ctx->stream, P);
             }
             break;
         }
@@ -418,14 +532,14 @@ int dispatchReSTIR(rt_shader sh, int kernel, int gx, int gy) {
             if ((rc = needPlanes(sh, kernel, "Candidates", LAYOUT_RESERVOIR_PLANES, P.cand)) || (rc = checkCount(P.cand, "Candidates"))) return rc;
             if ((rc = needPlanes(sh, kernel, "CandidatesB", LAYOUT_RESERVOIR_PLANES, P.candB)) || (rc = checkCount(P.candB, "CandidatesB"))) return rc;
             if ((rc = needTex(sh, kernel, "DepthBuffer", true, X, Y, P.depth))) return rc;
-            if (blocks) hipLaunchKernelGGL(k_spatial, dim3(blocks), dim3(256), 0, ctx->stream, P);
+            if (blocks) { LaunchScope ls(ctx, IK_SPATIAL, &P); hipLaunchKernelGGL(k_spatial, dim3(blocks), dim3(256), 0, ctx->stream, P); }
             break;
         }
         case 2: {  // TransferToOriginal
             if ((rc = needPlanes(sh, kernel, "Candidates", LAYOUT_RESERVOIR_PLANES, P.cand)) || (rc = checkCount(P.cand, "Candidates"))) return rc;
             if ((rc = needPlanes(sh, kernel, "CandidatesB", LAYOUT_RESERVOIR_PLANES, P.candB)) || (rc = checkCount(P.candB, "CandidatesB"))) return rc;
             if ((rc = needTex(sh, kernel, "DepthBuffer", true, X, Y, P.depth))) return rc;
-            if (blocks) hipLaunchKernelGGL(k_transfer, dim3(blocks), dim3(256), 0, ctx->stream, P);
+            if (blocks) { LaunchScope ls(ctx, IK_TRANSFER, &P); hipLaunchKernelGGL(k_transfer, dim3(blocks), dim3(256), 0, ctx->stream, P); }
             break;
         }
         case 3: {  // TemporalReuse
@@ -434,7 +548,7 @@ int dispatchReSTIR(rt_shader sh, int kernel, int gx, int gy) {
             if ((rc = needTex(sh, kernel, "DepthBuffer", true, X, Y, P.depth))) return rc;
             if ((rc = needTex(sh, kernel, "RayHitPointsA", false, X, Y, P.hitA))) return rc;
             if ((rc = needTex(sh, kernel, "RayHitPointsB", false, X, Y, P.hitB))) return rc;
-            if (blocks) hipLaunchKernelGGL(k_temporal, dim3(blocks), dim3(256), 0, ctx->stream, P);
+            if (blocks) { LaunchScope ls(ctx, IK_TEMPORAL, &P); hipLaunchKernelGGL(k_temporal, dim3(blocks), dim3(256), 0, ctx->stream, P); }
             break;
         }
         case 4: {  // TraceRays
@@ -447,8 +561,11 @@ int dispatchReSTIR(rt_shader sh, int kernel, int gx, int gy) {
             optionalTex(sh, kernel, "EnvironmentMap", P.env);
             if (!blocks) break;
             size_t ldsBytes = (size_t)WAVES_PER_BLOCK * P.stackDepth * 64 * 4;
-            if (instr) hipLaunchKernelGGL(k_trace_rays<true>, dim3(blocks), dim3(256), ldsBytes, ctx->stream, P);
-            else hipLaunchKernelGGL(k_trace_rays<false>, dim3(blocks), dim3(256), ldsBytes, ctx->stream, P);
+            {
+                LaunchScope ls(ctx, IK_TRACE_RAYS, &P);
+                if (instr) hipLaunchKernelGGL(k_trace_rays<true>, dim3(blocks), dim3(256), ldsBytes, ctx->stream, P);
+                else hipLaunchKernelGGL(k_trace_rays<false>, dim3(blocks), dim3(256), ldsBytes, ctx->stream, P);
+            }
             break;
         }
         default: return fail(ctx, RT_ERR_INVALID_ARG, "ReSTIR_BVH_RayTracer has no kernel %d", kernel);
@@ -468,8 +585,11 @@ int dispatchPreCalc(rt_shader sh, int kernel, int gx) {
     // threads beyond the dispatched groups do not run, exactly as with the reference's dispatch
     uint64_t covered = (uint64_t)gx * 256;
     uint32_t n = trianglesNum < covered ? trianglesNum : (uint32_t)covered;
-    hipLaunchKernelGGL(k_calc_tri_normals, dim3((unsigned)gx), dim3(256), 0, ctx->stream, (rt_triangle*)bTris->dev, bTris->count,
-                       (const rt_vertex*)bVerts->dev, bVerts->count, n);
+    {
+        LaunchScope ls(ctx, IK_CALC_NORMALS, nullptr);
+        hipLaunchKernelGGL(k_calc_tri_normals, dim3((unsigned)gx), dim3(256), 0, ctx->stream, (rt_triangle*)bTris->dev, bTris->count,
+                           (const rt_vertex*)bVerts->dev, bVerts->count, n);
+    }
     HIP_TRY(ctx, hipGetLastError());
     bTris->version = ctx->versionCounter++;
     return RT_OK;
@@ -492,7 +612,7 @@ int dispatchPostProc(rt_shader sh, int kernel, int gx, int gy) {
     unsigned blocks = 0;
     int rc = pixelGrid(ctx, P, gx, gy, &blocks);
     if (rc) return rc;
-    if (blocks) hipLaunchKernelGGL(k_accumulate, dim3(blocks), dim3(256), 0, ctx->stream, P);
+    if (blocks) { LaunchScope ls(ctx, IK_ACCUMULATE, &P); hipLaunchKernelGGL(k_accumulate, dim3(blocks), dim3(256), 0, ctx->stream, P); }
     HIP_TRY(ctx, hipGetLastError());
     return RT_OK;
 }
@@ -512,7 +632,9 @@ int rt_create(int device_id, rt_ctx* out) {
     if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) return RT_ERR_NO_DEVICE;  // the only code object in this library
     rt_ctx ctx = new rt_ctx_s;
     ctx->device = device_id;
-    if (hipSetDevice(device_id) != hipSuccess || hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
+    if (hipSetDevice(device_id) != hipSuccess || hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess ||
+        hipMalloc((void**)&ctx->statsDev, IK_COUNT * 8 * sizeof(unsigned long long)) != hipSuccess ||
+        hipMemsetAsync(ctx->statsDev, 0, IK_COUNT * 8 * sizeof(unsigned long long), ctx->stream) != hipSuccess) {
         delete ctx;
         return RT_ERR_NO_DEVICE;
     }
@@ -527,6 +649,10 @@ void rt_destroy(rt_ctx ctx) {
     if (ctx->prep.wide) e = hipFree(ctx->prep.wide);
     if (ctx->prep.btri) e = hipFree(ctx->prep.btri);
     if (ctx->prep.objRoot) e = hipFree(ctx->prep.objRoot);
+    if (ctx->statsDev) e = hipFree(ctx->statsDev);
+    if (ctx->blockMapDev) e = hipFree(ctx->blockMapDev);
+    for (auto& t : ctx->pending) { e = hipEventDestroy(t.start); e = hipEventDestroy(t.stop); }
+    for (auto ev : ctx->freeEvents) e = hipEventDestroy(ev);
     e = hipStreamDestroy(ctx->stream);
     (void)e;
     delete ctx;
@@ -556,28 +682,13 @@ int rt_shader_open(rt_ctx ctx, const char* name, rt_shader* out) {
     else if (!strcmp(name, "PostProcessor")) kind = SH_POSTPROC;
     else return fail(ctx, RT_ERR_INVALID_ARG, "unknown shader '%s'", name);
     if (kind == SH_RIS) return fail(ctx, RT_ERR_INVALID_ARG, "shader 'RIS_BVH_RayTracer' is not built into this library yet");
-    int rc = useDevice(ctx);
-    if (rc) return rc;
     rt_shader sh = new rt_shader_s;
     sh->ctx = ctx;
     sh->kind = kind;
-    hipError_t e = hipMalloc((void**)&sh->statsDev, 64 * sizeof(unsigned long long));
-    if (e == hipSuccess) e = hipMemsetAsync(sh->statsDev, 0, 64 * sizeof(unsigned long long), ctx->stream);
-    if (e != hipSuccess) {
-        delete sh;
-        return fail(ctx, RT_ERR_NO_DEVICE, "shader open failed: %s", hipGetErrorString(e));
-    }
     *out = sh;
     return RT_OK;
 }
-void rt_shader_close(rt_shader sh) {
-    if (!sh) return;
-    hipError_t e = hipSetDevice(sh->ctx->device);
-    e = hipStreamSynchronize(sh->ctx->stream);
-    if (sh->statsDev) e = hipFree(sh->statsDev);
-    (void)e;
-    delete sh;
-}
+void rt_shader_close(rt_shader sh) { delete sh; }
 
 int rt_find_kernel(rt_shader sh, const char* name) {
     if (!sh || !name) return RT_ERR_INVALID_ARG;
@@ -797,18 +908,68 @@ int rt_enable_stats(rt_ctx ctx, int level) {
     ctx->statsLevel = level;
     return RT_OK;
 }
+static int readStats(rt_ctx ctx, int ik, rt_dispatch_stats* acc) {
+    unsigned long long h[8];
+    HIP_TRY(ctx, hipMemcpyAsync(h, ctx->statsDev + ik * 8, sizeof h, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipMemsetAsync(ctx->statsDev + ik * 8, 0, sizeof h, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    acc->rays += h[ST_RAYS]; acc->pops += h[ST_POPS]; acc->bvChecks += h[ST_BVCHECKS]; acc->objVisits += h[ST_OBJVISITS];
+    acc->triIters += h[ST_TRIITERS]; acc->triChecks += h[ST_TRICHECKS]; acc->validNeighbours += h[ST_NEIGHBOURS];
+    acc->activePixels += h[ST_ACTIVE];
+    return RT_OK;
+}
 int rt_get_stats(rt_shader sh, int kernel, rt_dispatch_stats* out) {
     if (!sh || !out || kernel < 0 || kernel >= 8) return RT_ERR_INVALID_ARG;
     rt_ctx ctx = sh->ctx;
     int rc = useDevice(ctx);
     if (rc) return rc;
-    unsigned long long h[8];
-    HIP_TRY(ctx, hipMemcpyAsync(h, sh->statsDev + kernel * 8, sizeof h, hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(ctx, hipMemsetAsync(sh->statsDev + kernel * 8, 0, sizeof h, ctx->stream));
+    memset(out, 0, sizeof *out);
+    if (sh->kind == SH_RESTIR) {
+        static const int map[5][2] = {{IK_PRIMARY, IK_CANDIDATES}, {IK_SPATIAL, -1}, {IK_TRANSFER, -1}, {IK_TEMPORAL, -1}, {IK_TRACE_RAYS, -1}};
+        if (kernel >= 5) return fail(ctx, RT_ERR_INVALID_ARG, "no kernel %d", kernel);
+        for (int j = 0; j < 2; j++)
+            if (map[kernel][j] >= 0 && (rc = readStats(ctx, map[kernel][j], out))) return rc;
+        return RT_OK;
+    }
+    if (sh->kind == SH_POSTPROC && kernel == 0) return readStats(ctx, IK_ACCUMULATE, out);
+    return fail(ctx, RT_ERR_INVALID_ARG, "no statistics are kept for this shader's kernel %d", kernel);
+}
+
+int rt_profile_enable(rt_ctx ctx, int timing) {
+    if (!ctx) return RT_ERR_INVALID_ARG;
+    int rc = useDevice(ctx);
+    if (rc) return rc;
+    if ((rc = drainTiming(ctx))) return rc;
+    ctx->timing = timing != 0;
+    return RT_OK;
+}
+int rt_profile_reset(rt_ctx ctx) {
+    if (!ctx) return RT_ERR_INVALID_ARG;
+    int rc = useDevice(ctx);
+    if (rc) return rc;
+    if ((rc = drainTiming(ctx))) return rc;
+    for (int i = 0; i < IK_COUNT; i++) { ctx->timeMs[i] = 0; ctx->launches[i] = 0; }
+    HIP_TRY(ctx, hipMemsetAsync(ctx->statsDev, 0, IK_COUNT * 8 * sizeof(unsigned long long), ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    out->rays = h[ST_RAYS]; out->pops = h[ST_POPS]; out->bvChecks = h[ST_BVCHECKS]; out->objVisits = h[ST_OBJVISITS];
-    out->triIters = h[ST_TRIITERS]; out->triChecks = h[ST_TRICHECKS]; out->validNeighbours = h[ST_NEIGHBOURS];
-    out->activePixels = h[ST_ACTIVE];
+    return RT_OK;
+}
+int rt_profile_get(rt_ctx ctx, const char* kernel_name, rt_kernel_profile* out) {
+    if (!ctx || !kernel_name || !out) return RT_ERR_INVALID_ARG;
+    int rc = useDevice(ctx);
+    if (rc) return rc;
+    int ik = -1;
+    for (int i = 0; i < IK_COUNT; i++) if (!strcmp(kernel_name, IK_NAMES[i])) ik = i;
+    if (ik < 0) return fail(ctx, RT_ERR_INVALID_ARG, "unknown kernel name '%s'", kernel_name);
+    if ((rc = drainTiming(ctx))) return rc;
+    memset(out, 0, sizeof *out);
+    out->launches = ctx->launches[ik];
+    out->milliseconds = ctx->timeMs[ik];
+    unsigned long long h[8];
+    HIP_TRY(ctx, hipMemcpyAsync(h, ctx->statsDev + ik * 8, sizeof h, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    out->stats.rays = h[ST_RAYS]; out->stats.pops = h[ST_POPS]; out->stats.bvChecks = h[ST_BVCHECKS];
+    out->stats.objVisits = h[ST_OBJVISITS]; out->stats.triIters = h[ST_TRIITERS]; out->stats.triChecks = h[ST_TRICHECKS];
+    out->stats.validNeighbours = h[ST_NEIGHBOURS]; out->stats.activePixels = h[ST_ACTIVE];
     return RT_OK;
 }
 
