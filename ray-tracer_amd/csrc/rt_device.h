@@ -93,8 +93,10 @@ struct KParams {
     // band + instrumentation
     int32_t row0, row1;
     const uint32_t* blockMap;  // launch block index -> (by << 16 | bx) of the 16x16-pixel block it renders, ~0u = none
-    unsigned long long* stats;  // 8 counters (rt_dispatch_stats order) or null
+    unsigned long long* stats;  // sharded counters (rt_dispatch_stats order) or null
+    int32_t statsLevel;         // 1: rays only, 2: everything
     uint32_t* records;          // 8 dwords per pixel (trace record) or null
+    unsigned long long* waveProfile;  // diagnostics: 4 qwords per wave of the launch (start, end, max iterations, sum iterations) or null
 };
 
 // Trace record written when a "TraceRecords" buffer is bound (8 dwords per pixel):

@@ -202,7 +202,7 @@ struct Trav {
     int triChecks, bvChecks;  // debugData of RS:184,202,265,267
     // instrumentation (INSTR only)
     uint32_t hash;
-    uint32_t pops, objVisits, triIters;
+    uint32_t pops, objVisits, triIters, iters;
 };
 
 DEV float RayBVIntersect(v3 pos, v3 inv, v3 bmin, v3 bmax) {  // RS:148-161
@@ -228,11 +228,12 @@ DEV void traverse(const KParams& P, const v3 wpos, const v3 wdir, const v3 winv,
     int sp = 0, objBase = -1, objCur = 0, objEnd = 0, curObj = -1, localTri = -1;
     float localU = 0, localV = 0;
     t.tri = -1; t.obj = -1; t.u = 0; t.v = 0; t.triChecks = 0; t.bvChecks = 0;
-    if (INSTR) { t.hash = 2166136261u; t.pops = 0; t.objVisits = 0; t.triIters = 0; }
+    if (INSTR) { t.hash = 2166136261u; t.pops = 0; t.objVisits = 0; t.triIters = 0; t.iters = 0; }
     const int cap = P.stackDepth;
     stk[0] = P.sceneRootEntry;
     sp = 1;
     for (;;) {
+        if (INSTR) t.iters++;
         if (objBase < 0) {
             if (objCur < objEnd) {
                 // next scene object of the current scene-level leaf (RS:235-246)
@@ -353,10 +354,14 @@ DEV HitInfo resolveHit(const KParams& P, const Trav& t, v3 wpos, v3 wdir) {
 }
 
 // ---------------- wave-level counters ----------------
+// Counters are kept in STAT_SHARDS copies, 8 counters each; a workgroup adds into the copy chosen by its index, so
+// the atomics of one launch spread over many addresses instead of serialising on one (a single contended word
+// retires only ~one atomic per 12 ns).  The host sums the copies.
+constexpr int STAT_SHARDS = 64;
 DEV void waveAdd(unsigned long long* dst, uint32_t v) {
     // butterfly sum over the 64 lanes (inactive lanes contribute their own v, so callers pass 0 for them)
     for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-    if ((threadIdx.x & 63) == 0 && v) atomicAdd(dst, (unsigned long long)v);
+    if ((threadIdx.x & 63) == 0 && v) atomicAdd(dst + (blockIdx.x % STAT_SHARDS) * 8, (unsigned long long)v);
 }
 enum { ST_RAYS = 0, ST_POPS, ST_BVCHECKS, ST_OBJVISITS, ST_TRIITERS, ST_TRICHECKS, ST_NEIGHBOURS, ST_ACTIVE };
 
@@ -431,7 +436,9 @@ __global__ __launch_bounds__(256) void k_primary(const KParams P) {
     const Pixel px = pixelOfThread(P);
     uint32_t rays = 0;
     Trav t;
-    if (INSTR) { t.pops = t.objVisits = t.triIters = 0; t.triChecks = t.bvChecks = 0; }
+    if (INSTR) { t.pops = t.objVisits = t.triIters = t.iters = 0; t.triChecks = t.bvChecks = 0; }
+    unsigned long long tStart = 0;
+    if (INSTR && P.waveProfile) tStart = wall_clock64();
     if (px.active) {
         const uint32_t idx = (uint32_t)px.x, idy = (uint32_t)px.y;
         uint32_t state = idy * (uint32_t)P.ResX + idx + P.FrameRand;
@@ -468,10 +475,18 @@ __global__ __launch_bounds__(256) void k_primary(const KParams P) {
             r[5] = 0; r[6] = 0xffffffffu; r[7] = 0;
         }
     }
+    if (INSTR && P.waveProfile) {
+        uint32_t it = px.active ? t.iters : 0, mx = it, sm = it;
+        for (int off = 32; off > 0; off >>= 1) { uint32_t o = __shfl_xor(mx, off, 64); mx = o > mx ? o : mx; sm += __shfl_xor(sm, off, 64); }
+        if ((threadIdx.x & 63) == 0) {
+            unsigned long long* w = P.waveProfile + ((size_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 4;
+            w[0] = tStart; w[1] = wall_clock64(); w[2] = mx; w[3] = sm;
+        }
+    }
     if (P.stats) {
         waveAdd(P.stats + ST_RAYS, rays);
-        waveAdd(P.stats + ST_ACTIVE, px.active ? 1u : 0u);
         if (INSTR) {
+            waveAdd(P.stats + ST_ACTIVE, px.active ? 1u : 0u);
             waveAdd(P.stats + ST_POPS, px.active ? t.pops : 0);
             waveAdd(P.stats + ST_BVCHECKS, px.active ? (uint32_t)t.bvChecks : 0);
             waveAdd(P.stats + ST_OBJVISITS, px.active ? t.objVisits : 0);
@@ -636,7 +651,7 @@ __global__ __launch_bounds__(256) void k_temporal(const KParams P) {
             storeReservoir(P.temporal, pixelIndex, thisFrame);
         }
     }
-    if (P.stats) waveAdd(P.stats + ST_ACTIVE, active ? 1u : 0u);
+    if (P.stats && P.statsLevel >= 2) waveAdd(P.stats + ST_ACTIVE, active ? 1u : 0u);
 }
 
 // =====================================================================================================
@@ -680,7 +695,7 @@ __global__ __launch_bounds__(256) void k_spatial(const KParams P) {
         }
         storeReservoir(dstb, pixelBaseIndex, sp);
     }
-    if (P.stats) { waveAdd(P.stats + ST_ACTIVE, active ? 1u : 0u); waveAdd(P.stats + ST_NEIGHBOURS, neighbours); }
+    if (P.stats && P.statsLevel >= 2) { waveAdd(P.stats + ST_ACTIVE, active ? 1u : 0u); waveAdd(P.stats + ST_NEIGHBOURS, neighbours); }
 }
 
 // TransferToOriginal (RS:575-582)
@@ -695,7 +710,7 @@ __global__ __launch_bounds__(256) void k_transfer(const KParams P) {
         P.cand.p2[i] = P.candB.p2[i];
         P.cand.p3[i] = P.candB.p3[i];
     }
-    if (P.stats) waveAdd(P.stats + ST_ACTIVE, active ? 1u : 0u);
+    if (P.stats && P.statsLevel >= 2) waveAdd(P.stats + ST_ACTIVE, active ? 1u : 0u);
 }
 
 // =====================================================================================================
@@ -792,8 +807,8 @@ __global__ __launch_bounds__(256) void k_trace_rays(const KParams P) {
     }
     if (P.stats) {
         waveAdd(P.stats + ST_RAYS, rays);
-        waveAdd(P.stats + ST_ACTIVE, px.active ? 1u : 0u);
         if (INSTR) {
+            waveAdd(P.stats + ST_ACTIVE, px.active ? 1u : 0u);
             waveAdd(P.stats + ST_POPS, pops); waveAdd(P.stats + ST_BVCHECKS, bvc); waveAdd(P.stats + ST_OBJVISITS, objv);
             waveAdd(P.stats + ST_TRIITERS, trii); waveAdd(P.stats + ST_TRICHECKS, tric);
         }

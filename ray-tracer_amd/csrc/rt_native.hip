@@ -34,7 +34,7 @@ struct rt_ctx_s {
     std::string err;
     int row0 = 0, row1 = 0;
     int statsLevel = 0;  // 0 off, 1 rays + active pixels, 2 all counters (instrumented kernel variants)
-    unsigned long long* statsDev = nullptr;  // IK_COUNT x 8 counters, accumulated until read
+    unsigned long long* statsDev = nullptr;  // IK_COUNT x STAT_SHARDS x 8 counters, accumulated until read
     // workgroup -> image block table of the per-pixel kernels (see buildBlockMap)
     uint32_t* blockMapDev = nullptr;
     size_t blockMapCap = 0;
@@ -298,6 +298,8 @@ int prepareScene(rt_shader sh, int kernel, KParams& P) {
     P.mats = (const rt_material*)bMats->dev; P.nMats = bMats->count;
     P.sceneRootEntry = pr.sceneRootEntry;
     P.stackDepth = pr.stackDepth;
+    static const bool diagNoTraverse = getenv("RT_DIAG_NO_TRAVERSE") != nullptr;  // timing experiments only: every ray misses
+    if (diagNoTraverse) P.stackDepth = 0;
     return RT_OK;
 }
 
@@ -443,7 +445,7 @@ struct LaunchScope {
     int ik;
     hipEvent_t start = nullptr, stop = nullptr;
     LaunchScope(rt_ctx c, int k, KParams* P) : ctx(c), ik(k) {
-        if (P) P->stats = ctx->statsLevel > 0 ? ctx->statsDev + k * 8 : nullptr;
+        if (P) { P->stats = ctx->statsLevel > 0 ? ctx->statsDev + (size_t)k * STAT_SHARDS * 8 : nullptr; P->statsLevel = ctx->statsLevel; }
         ctx->launches[k]++;
         if (!ctx->timing) return;
         auto take = [&]() -> hipEvent_t {
@@ -495,6 +497,11 @@ int dispatchReSTIR(rt_shader sh, int kernel, int gx, int gy) {
     if (rec) {
         if (rec->stride != RECORD_DWORDS * 4 || rec->count < npx) return fail(ctx, RT_ERR_INVALID_ARG, "TraceRecords must have stride 32 and one record per pixel");
         P.records = (uint32_t*)rec->dev;
+        instr = true;
+    }
+    if (rt_buffer wp = boundBuffer(sh, kernel, "WaveProfile")) {  // diagnostics, kernel 0 only
+        if (wp->stride != 32 || wp->count < (int64_t)blocks * 4) return fail(ctx, RT_ERR_INVALID_ARG, "WaveProfile needs stride 32 and %u records", blocks * 4);
+        P.waveProfile = (unsigned long long*)wp->dev;
         instr = true;
     }
     if (ctx->statsLevel >= 2) instr = true;
@@ -633,8 +640,8 @@ int rt_create(int device_id, rt_ctx* out) {
     rt_ctx ctx = new rt_ctx_s;
     ctx->device = device_id;
     if (hipSetDevice(device_id) != hipSuccess || hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess ||
-        hipMalloc((void**)&ctx->statsDev, IK_COUNT * 8 * sizeof(unsigned long long)) != hipSuccess ||
-        hipMemsetAsync(ctx->statsDev, 0, IK_COUNT * 8 * sizeof(unsigned long long), ctx->stream) != hipSuccess) {
+        hipMalloc((void**)&ctx->statsDev, IK_COUNT * STAT_SHARDS * 8 * sizeof(unsigned long long)) != hipSuccess ||
+        hipMemsetAsync(ctx->statsDev, 0, IK_COUNT * STAT_SHARDS * 8 * sizeof(unsigned long long), ctx->stream) != hipSuccess) {
         delete ctx;
         return RT_ERR_NO_DEVICE;
     }
@@ -908,11 +915,19 @@ int rt_enable_stats(rt_ctx ctx, int level) {
     ctx->statsLevel = level;
     return RT_OK;
 }
+static int fetchStats(rt_ctx ctx, int ik, bool reset, unsigned long long h[8]) {
+    unsigned long long raw[STAT_SHARDS * 8];
+    unsigned long long* src = ctx->statsDev + (size_t)ik * STAT_SHARDS * 8;
+    HIP_TRY(ctx, hipMemcpyAsync(raw, src, sizeof raw, hipMemcpyDeviceToHost, ctx->stream));
+    if (reset) HIP_TRY(ctx, hipMemsetAsync(src, 0, sizeof raw, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    for (int c = 0; c < 8; c++) { h[c] = 0; for (int s = 0; s < STAT_SHARDS; s++) h[c] += raw[s * 8 + c]; }
+    return RT_OK;
+}
 static int readStats(rt_ctx ctx, int ik, rt_dispatch_stats* acc) {
     unsigned long long h[8];
-    HIP_TRY(ctx, hipMemcpyAsync(h, ctx->statsDev + ik * 8, sizeof h, hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(ctx, hipMemsetAsync(ctx->statsDev + ik * 8, 0, sizeof h, ctx->stream));
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    int rc = fetchStats(ctx, ik, true, h);
+    if (rc) return rc;
     acc->rays += h[ST_RAYS]; acc->pops += h[ST_POPS]; acc->bvChecks += h[ST_BVCHECKS]; acc->objVisits += h[ST_OBJVISITS];
     acc->triIters += h[ST_TRIITERS]; acc->triChecks += h[ST_TRICHECKS]; acc->validNeighbours += h[ST_NEIGHBOURS];
     acc->activePixels += h[ST_ACTIVE];
@@ -949,7 +964,7 @@ int rt_profile_reset(rt_ctx ctx) {
     if (rc) return rc;
     if ((rc = drainTiming(ctx))) return rc;
     for (int i = 0; i < IK_COUNT; i++) { ctx->timeMs[i] = 0; ctx->launches[i] = 0; }
-    HIP_TRY(ctx, hipMemsetAsync(ctx->statsDev, 0, IK_COUNT * 8 * sizeof(unsigned long long), ctx->stream));
+    HIP_TRY(ctx, hipMemsetAsync(ctx->statsDev, 0, IK_COUNT * STAT_SHARDS * 8 * sizeof(unsigned long long), ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return RT_OK;
 }
@@ -965,8 +980,7 @@ int rt_profile_get(rt_ctx ctx, const char* kernel_name, rt_kernel_profile* out) 
     out->launches = ctx->launches[ik];
     out->milliseconds = ctx->timeMs[ik];
     unsigned long long h[8];
-    HIP_TRY(ctx, hipMemcpyAsync(h, ctx->statsDev + ik * 8, sizeof h, hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if ((rc = fetchStats(ctx, ik, false, h))) return rc;
     out->stats.rays = h[ST_RAYS]; out->stats.pops = h[ST_POPS]; out->stats.bvChecks = h[ST_BVCHECKS];
     out->stats.objVisits = h[ST_OBJVISITS]; out->stats.triIters = h[ST_TRIITERS]; out->stats.triChecks = h[ST_TRICHECKS];
     out->stats.validNeighbours = h[ST_NEIGHBOURS]; out->stats.activePixels = h[ST_ACTIVE];
