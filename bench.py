@@ -139,6 +139,7 @@ def main():
             if name in iprof:
                 c = {k: v / iprof[name]["launches"] for k, v in iprof[name].items() if k not in ("launches", "ms")}
                 b = algorithmic_bytes(name, c, band_px)
+                entry["counters_per_launch"] = {k: round(v) for k, v in c.items() if v}
                 entry["algorithmic_MB_per_launch"] = b / 1e6
                 entry["achieved_GBs"] = b / 1e9 / (ms / 1e3) if ms > 0 else None
             kernels[name] = entry

@@ -97,6 +97,7 @@ struct KParams {
     int32_t statsLevel;         // 1: rays only, 2: everything
     uint32_t* records;          // 8 dwords per pixel (trace record) or null
     unsigned long long* waveProfile;  // diagnostics: 4 qwords per wave of the launch (start, end, max iterations, sum iterations) or null
+    int32_t waveProfileKernel;        // which kernel writes it: 0 primary, 1 candidates, 2 trace_rays
 };
 
 // Trace record written when a "TraceRecords" buffer is bound (8 dwords per pixel):

@@ -23,6 +23,14 @@ namespace rtn {
 constexpr float PI_F = 3.1415926f;        // Constants.hlsl:3
 constexpr uint32_t MAX_BVH_DEPTH = 32;    // Constants.hlsl:14
 constexpr int WAVES_PER_BLOCK = 4;
+#ifndef RT_TRAVERSE_V
+#define RT_TRAVERSE_V 2
+#endif
+#if RT_TRAVERSE_V == 1
+#define TRAVERSE traverse
+#else
+#define TRAVERSE traverse2
+#endif
 
 struct v2 { float x, y; };
 struct v3 { float x, y, z; };
@@ -323,6 +331,149 @@ DEV void traverse(const KParams& P, const v3 wpos, const v3 wdir, const v3 winv,
     t.dst = worldBest;
 }
 
+// ---- second formulation of the same traversal, organised for 64-lane execution -------------------------------
+// The entry to visit next stays in a register (`e`); only the FAR child of an internal node goes to the LDS stack
+// (the reference pushes far then near and pops near at once: same order, half the stack traffic).  Each trip of
+// the outer loop runs an internal-node phase — every lane that holds an internal entry steps down the tree until
+// it holds a leaf, or is done, or enough lanes are waiting with a leaf — and then a leaf phase in which the waiting
+// lanes test their triangles together.  Keeping the two kinds of work in separate phases is what keeps the 64
+// lanes on the same instructions: in a single mixed loop nearly every trip pays for both.
+constexpr uint32_t ENTRY_NONE = 0xffffffffu;  // no entry held: take one from the stack (never a valid entry: an
+                                              // inline leaf with count 31 at start 2^26-1 is rejected at build)
+struct TravState {
+    v3 rpos, rdir, rinv;     // ray of the level being traversed (world at scene level, object space inside an object)
+    float best, worldBest;   // hitInfo.dst of the level being traversed / of the world level
+    int sp, objBase, objCur, objEnd, curObj, localTri;
+    float localU, localV;
+};
+
+// Takes the next entry to visit: leaves an object whose subtree is exhausted (RS:251-258), enters the next scene
+// object of the current scene-level leaf (RS:235-246), or pops the stack.  Returns false when the ray is finished.
+template <bool INSTR>
+DEV bool nextEntry(const KParams& P, const v3 wpos, const v3 wdir, const v3 winv, uint32_t* stk, TravState& s, Trav& t,
+                   uint32_t& e) {
+    for (;;) {
+        if (s.objBase >= 0) {
+            if (s.sp != s.objBase) break;
+            if (s.best < s.worldBest) { s.worldBest = s.best; t.tri = s.localTri; t.obj = s.curObj; t.u = s.localU; t.v = s.localV; }
+            s.best = s.worldBest;
+            s.rpos = wpos; s.rdir = wdir; s.rinv = winv;
+            s.objBase = -1;
+        }
+        if (s.objCur < s.objEnd) {
+            const float* m = P.objs[s.objCur].worldToLocalMatrix.m;
+            s.rpos = mul44(m, wpos, 1.0f);
+            s.rdir = mul44(m, wdir, 0.0f);
+            s.rinv = rcp3(s.rdir);
+            s.best = INF();
+            s.localTri = -1;
+            s.curObj = s.objCur;
+            s.objBase = s.sp;
+            e = P.objRootEntry[s.objCur];
+            s.objCur++;
+            if (INSTR) { t.objVisits++; t.pops++; }
+            return true;
+        }
+        if (s.sp == 0) { e = ENTRY_NONE; return false; }
+        break;
+    }
+    --s.sp;
+    e = s.sp < P.stackDepth ? stk[s.sp * 64] : ENTRY_LEAF;
+    if (INSTR) t.pops++;
+    return true;
+}
+
+template <bool INSTR>
+DEV void traverse2(const KParams& P, const v3 wpos, const v3 wdir, const v3 winv, uint32_t* stk, Trav& t) {
+    TravState s;
+    s.rpos = wpos; s.rdir = wdir; s.rinv = winv;
+    s.best = INF(); s.worldBest = INF();
+    s.sp = 0; s.objBase = -1; s.objCur = 0; s.objEnd = 0; s.curObj = -1; s.localTri = -1;
+    s.localU = 0; s.localV = 0;
+    t.tri = -1; t.obj = -1; t.u = 0; t.v = 0; t.triChecks = 0; t.bvChecks = 0;
+    if (INSTR) { t.hash = 2166136261u; t.pops = 1; t.objVisits = 0; t.triIters = 0; t.iters = 0; }
+    const int cap = P.stackDepth;
+    uint32_t e = P.sceneRootEntry;
+    bool alive = true;
+    while (__builtin_amdgcn_ballot_w64(alive) != 0) {
+        // ---------- internal-node phase ----------
+        for (;;) {
+            const bool isInt = alive && (e & (ENTRY_LEAF | ENTRY_LEAF_INDIRECT)) == 0;
+            const unsigned long long intMask = __builtin_amdgcn_ballot_w64(isInt);
+            if (intMask == 0) break;
+            if (isInt) {
+                if (INSTR) { t.iters++; t.hash = (t.hash ^ (0x80000000u | e)) * 16777619u; }
+                const float4* rec = P.wide + (int64_t)e * 4;
+                const float4 q0 = rec[0], q1 = rec[1], q2 = rec[2], q3 = rec[3];
+                const float dstA = RayBVIntersect(s.rpos, s.rinv, V3(q0.x, q0.y, q0.z), V3(q0.w, q1.x, q1.y));
+                const float dstB = RayBVIntersect(s.rpos, s.rinv, V3(q1.z, q1.w, q2.x), V3(q2.y, q2.z, q2.w));
+                t.bvChecks += 2;
+                const uint32_t eA = __float_as_uint(q3.x), eB = __float_as_uint(q3.y);
+                const bool aFirst = dstA < dstB;  // RS:204-214: the nearer child is visited first
+                const uint32_t eNear = aFirst ? eA : eB, eFar = aFirst ? eB : eA;
+                const bool nearHit = (aFirst ? dstA : dstB) < s.best, farHit = (aFirst ? dstB : dstA) < s.best;
+                if (nearHit) {
+                    if (farHit) { if (s.sp < cap) stk[s.sp * 64] = eFar; s.sp++; }
+                    e = eNear;
+                    if (INSTR) t.pops++;
+                } else if (farHit) {
+                    e = eFar;
+                    if (INSTR) t.pops++;
+                } else {
+                    alive = nextEntry<INSTR>(P, wpos, wdir, winv, stk, s, t, e);
+                }
+            }
+            // leave the phase early once at least half of the lanes still at work are waiting with a leaf
+            const unsigned long long leafMask = __builtin_amdgcn_ballot_w64(alive && (e & (ENTRY_LEAF | ENTRY_LEAF_INDIRECT)) != 0);
+            if (2 * __builtin_popcountll(leafMask) >= __builtin_popcountll(__builtin_amdgcn_ballot_w64(alive))) break;
+        }
+        // ---------- leaf phase ----------
+        if (alive && (e & (ENTRY_LEAF | ENTRY_LEAF_INDIRECT)) != 0) {
+            int start, count;
+            if (e & ENTRY_LEAF) {
+                start = (int)(e & (uint32_t)ENTRY_INLINE_MAX_START);
+                count = (int)((e >> 26) & 31u);
+                if (INSTR) { t.hash = (t.hash ^ (uint32_t)start) * 16777619u; t.hash = (t.hash ^ (uint32_t)count) * 16777619u; }
+            } else {
+                const rt_bv* bv = &P.BVs[e & ENTRY_INDEX_MASK];
+                int a = bv->indexA, b = bv->indexB;
+                if (INSTR) { t.hash = (t.hash ^ (uint32_t)a) * 16777619u; t.hash = (t.hash ^ (uint32_t)b) * 16777619u; }
+                start = a < 0 ? -a : a;
+                count = b < 0 ? -b : b;
+            }
+            if (INSTR) t.iters++;
+            if (s.objBase < 0) {  // scene-level leaf: a run of scene objects
+                s.objCur = start;
+                s.objEnd = start + count;
+            } else {
+                for (int triIndex = start; triIndex < start + count; triIndex++) {  // RS:179-193
+                    const float4* rec = P.btri + (int64_t)triIndex * 4;
+                    const float4 q3 = rec[3];
+                    if (INSTR) t.triIters++;
+                    if (dot(V3(q3.x, q3.y, q3.z), s.rdir) <= 0) {
+                        const float4 q0 = rec[0], q1 = rec[1], q2 = rec[2];
+                        v3 edgeAB = V3(q1.x, q1.y, q1.z), edgeAC = V3(q2.x, q2.y, q2.z);
+                        v3 normalVector = V3(q0.w, q1.w, q2.w);
+                        v3 ao = s.rpos - V3(q0.x, q0.y, q0.z);
+                        v3 dao = cross(ao, s.rdir);
+                        float determinant = -dot(s.rdir, normalVector);
+                        float invDet = 1 / determinant;
+                        float dst = dot(ao, normalVector) * invDet;
+                        float u = dot(edgeAC, dao) * invDet;
+                        float v = -dot(edgeAB, dao) * invDet;
+                        float w = 1 - u - v;
+                        bool didHit = determinant >= 1E-8f && dst >= 0 && u >= 0 && v >= 0 && w >= 0;
+                        t.triChecks++;
+                        if (didHit && dst < s.best) { s.best = dst; s.localU = u; s.localV = v; s.localTri = triIndex; }
+                    }
+                }
+            }
+            alive = nextEntry<INSTR>(P, wpos, wdir, winv, stk, s, t, e);
+        }
+    }
+    t.dst = s.worldBest;
+}
+
 // Shading data of a traversal result, as TraverseSceneBVH leaves it in hitInfo (RS:248-258).
 struct HitInfo { float dst; v3 hitPoint; v2 uv; v3 normal; v3 incomingDir; int materialIndex; };
 DEV HitInfo resolveHit(const KParams& P, const Trav& t, v3 wpos, v3 wdir) {
@@ -362,6 +513,15 @@ DEV void waveAdd(unsigned long long* dst, uint32_t v) {
     // butterfly sum over the 64 lanes (inactive lanes contribute their own v, so callers pass 0 for them)
     for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
     if ((threadIdx.x & 63) == 0 && v) atomicAdd(dst + (blockIdx.x % STAT_SHARDS) * 8, (unsigned long long)v);
+}
+// Diagnostics (instrumented variants only): lifetime and loop-trip counts of each wave of a launch.
+DEV void writeWaveProfile(const KParams& P, unsigned long long tStart, uint32_t iters) {
+    uint32_t mx = iters, sm = iters;
+    for (int off = 32; off > 0; off >>= 1) { uint32_t o = __shfl_xor(mx, off, 64); mx = o > mx ? o : mx; sm += __shfl_xor(sm, off, 64); }
+    if ((threadIdx.x & 63) == 0) {
+        unsigned long long* w = P.waveProfile + ((size_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 4;
+        w[0] = tStart; w[1] = wall_clock64(); w[2] = mx; w[3] = sm;
+    }
 }
 enum { ST_RAYS = 0, ST_POPS, ST_BVCHECKS, ST_OBJVISITS, ST_TRIITERS, ST_TRICHECKS, ST_NEIGHBOURS, ST_ACTIVE };
 
@@ -450,7 +610,7 @@ __global__ __launch_bounds__(256) void k_primary(const KParams P) {
         v3 rpos = V3(P.camPos[0], P.camPos[1], P.camPos[2]) + jitter * P.FocalPlaneFactor;
         v3 rdir = normalize(worldFocalPos - rpos);
 
-        traverse<INSTR>(P, rpos, rdir, rcp3(rdir), laneStack(lds, P.stackDepth), t);
+        TRAVERSE<INSTR>(P, rpos, rdir, rcp3(rdir), laneStack(lds, P.stackDepth), t);
         rays = 1;
         HitInfo h = resolveHit(P, t, rpos, rdir);
         const bool didHit = h.dst != INF();
@@ -475,14 +635,7 @@ __global__ __launch_bounds__(256) void k_primary(const KParams P) {
             r[5] = 0; r[6] = 0xffffffffu; r[7] = 0;
         }
     }
-    if (INSTR && P.waveProfile) {
-        uint32_t it = px.active ? t.iters : 0, mx = it, sm = it;
-        for (int off = 32; off > 0; off >>= 1) { uint32_t o = __shfl_xor(mx, off, 64); mx = o > mx ? o : mx; sm += __shfl_xor(sm, off, 64); }
-        if ((threadIdx.x & 63) == 0) {
-            unsigned long long* w = P.waveProfile + ((size_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 4;
-            w[0] = tStart; w[1] = wall_clock64(); w[2] = mx; w[3] = sm;
-        }
-    }
+    if (INSTR && P.waveProfile && P.waveProfileKernel == 0) writeWaveProfile(P, tStart, px.active ? t.iters : 0);
     if (P.stats) {
         waveAdd(P.stats + ST_RAYS, rays);
         if (INSTR) {
@@ -543,7 +696,9 @@ __global__ __launch_bounds__(256) void k_candidates(const KParams P) {
     const Pixel px = pixelOfThread(P);
     uint32_t rays = 0;
     Trav t;
-    if (INSTR) { t.pops = t.objVisits = t.triIters = 0; t.triChecks = t.bvChecks = 0; }
+    if (INSTR) { t.pops = t.objVisits = t.triIters = t.iters = 0; t.triChecks = t.bvChecks = 0; }
+    unsigned long long tStart = 0;
+    if (INSTR && P.waveProfile) tStart = wall_clock64();
     if (px.active) {
         const uint32_t idx = (uint32_t)px.x, idy = (uint32_t)px.y;
         const int64_t i = (int64_t)idy * P.ResX + idx;
@@ -588,7 +743,7 @@ __global__ __launch_bounds__(256) void k_candidates(const KParams P) {
                 v2 wb = GenerateCandidateWeight(P, sqrDst, hitAngleDot, hitInfo.incomingDir, dir, hitInfo.normal,
                                                 metallicity, roughness, lightObject.brightness);
                 if (P.kwVisReuse) {  // RS:422-430
-                    traverse<INSTR>(P, hitInfo.hitPoint, dir, rcp3(dir), laneStack(lds, P.stackDepth), t);
+                    TRAVERSE<INSTR>(P, hitInfo.hitPoint, dir, rcp3(dir), laneStack(lds, P.stackDepth), t);
                     rays = 1;
                     int shadowMat = t.obj >= 0 ? P.objs[t.obj].materialIndex : 0;
                     if (loadMaterial(P, shadowMat).brightness == 0) wb.x = 0;
@@ -600,6 +755,7 @@ __global__ __launch_bounds__(256) void k_candidates(const KParams P) {
             if ((int64_t)pixelIndex < P.cand.count) storeReservoir(P.cand, pixelIndex, res);
         }
     }
+    if (INSTR && P.waveProfile && P.waveProfileKernel == 1) writeWaveProfile(P, tStart, rays ? t.iters : 0);
     if (P.stats) {
         waveAdd(P.stats + ST_RAYS, rays);
         if (INSTR) {
@@ -729,7 +885,9 @@ template <bool INSTR>
 __global__ __launch_bounds__(256) void k_trace_rays(const KParams P) {
     extern __shared__ uint32_t lds[];
     const Pixel px = pixelOfThread(P);
-    uint32_t rays = 0, pops = 0, bvc = 0, objv = 0, trii = 0, tric = 0;
+    uint32_t rays = 0, pops = 0, bvc = 0, objv = 0, trii = 0, tric = 0, iters = 0;
+    unsigned long long tStart = 0;
+    if (INSTR && P.waveProfile) tStart = wall_clock64();
     if (px.active) {
         const uint32_t idx = (uint32_t)px.x, idy = (uint32_t)px.y;
         uint32_t state = idy * (uint32_t)P.ResX + idx + P.FrameRand;
@@ -786,9 +944,10 @@ __global__ __launch_bounds__(256) void k_trace_rays(const KParams P) {
                 else indirectLight = indirectLight + emittedLight * rayColor;
                 if (bounceCount != P.MaxBounceCount) {
                     Trav t;
-                    traverse<INSTR>(P, rpos, rdir, rinv, laneStack(lds, P.stackDepth), t);
+                    TRAVERSE<INSTR>(P, rpos, rdir, rinv, laneStack(lds, P.stackDepth), t);
                     rays++;
                     if (INSTR) {
+                        iters += t.iters;
                         pops += t.pops; bvc += (uint32_t)t.bvChecks; objv += t.objVisits; trii += t.triIters;
                         tric += (uint32_t)t.triChecks;
                         // chain the per-ray hashes the way one running hash over all rays would evolve
@@ -805,6 +964,7 @@ __global__ __launch_bounds__(256) void k_trace_rays(const KParams P) {
             if (INSTR && P.records && rays) P.records[i * RECORD_DWORDS + 7] = hash;
         }
     }
+    if (INSTR && P.waveProfile && P.waveProfileKernel == 2) writeWaveProfile(P, tStart, iters);
     if (P.stats) {
         waveAdd(P.stats + ST_RAYS, rays);
         if (INSTR) {

@@ -78,6 +78,7 @@ struct rt_texture_s {
     rt_format format;
     void* dev;     // float (R32F) or float4 (others) texels
     size_t bytes;  // device bytes
+    uint64_t version;  // bumped by every upload
 };
 
 struct rt_shader_s {
@@ -499,9 +500,11 @@ int dispatchReSTIR(rt_shader sh, int kernel, int gx, int gy) {
         P.records = (uint32_t*)rec->dev;
         instr = true;
     }
-    if (rt_buffer wp = boundBuffer(sh, kernel, "WaveProfile")) {  // diagnostics, kernel 0 only
-        if (wp->stride != 32 || wp->count < (int64_t)blocks * 4) return fail(ctx, RT_ERR_INVALID_ARG, "WaveProfile needs stride 32 and %u records", blocks * 4);
+    if (rt_buffer wp = boundBuffer(sh, kernel, "WaveProfile")) {  // diagnostics
+        if (wp->stride != 32 || wp->count < (int64_t)blocks * 8 + 64) return fail(ctx, RT_ERR_INVALID_ARG, "WaveProfile needs stride 32 and %u records", blocks * 8 + 64);
         P.waveProfile = (unsigned long long*)wp->dev;
+        static const int which = [] { const char* e = getenv("RT_WAVE_PROFILE_KERNEL"); return e ? atoi(e) : 0; }();
+        P.waveProfileKernel = which;
         instr = true;
     }
     if (ctx->statsLevel >= 2) instr = true;
@@ -539,14 +542,16 @@ int dispatchReSTIR(rt_shader sh, int kernel, int gx, int gy) {
             if ((rc = needPlanes(sh, kernel, "Candidates", LAYOUT_RESERVOIR_PLANES, P.cand)) || (rc = checkCount(P.cand, "Candidates"))) return rc;
             if ((rc = needPlanes(sh, kernel, "CandidatesB", LAYOUT_RESERVOIR_PLANES, P.candB)) || (rc = checkCount(P.candB, "CandidatesB"))) return rc;
             if ((rc = needTex(sh, kernel, "DepthBuffer", true, X, Y, P.depth))) return rc;
-            if (blocks) { LaunchScope ls(ctx, IK_SPATIAL, &P); hipLaunchKernelGGL(k_spatial, dim3(blocks), dim3(256), 0, ctx->stream, P); }
+            if (!blocks) break;
+            { LaunchScope ls(ctx, IK_SPATIAL, &P); hipLaunchKernelGGL(k_spatial, dim3(blocks), dim3(256), 0, ctx->stream, P); }
             break;
         }
         case 2: {  // TransferToOriginal
             if ((rc = needPlanes(sh, kernel, "Candidates", LAYOUT_RESERVOIR_PLANES, P.cand)) || (rc = checkCount(P.cand, "Candidates"))) return rc;
             if ((rc = needPlanes(sh, kernel, "CandidatesB", LAYOUT_RESERVOIR_PLANES, P.candB)) || (rc = checkCount(P.candB, "CandidatesB"))) return rc;
             if ((rc = needTex(sh, kernel, "DepthBuffer", true, X, Y, P.depth))) return rc;
-            if (blocks) { LaunchScope ls(ctx, IK_TRANSFER, &P); hipLaunchKernelGGL(k_transfer, dim3(blocks), dim3(256), 0, ctx->stream, P); }
+            if (!blocks) break;
+            { LaunchScope ls(ctx, IK_TRANSFER, &P); hipLaunchKernelGGL(k_transfer, dim3(blocks), dim3(256), 0, ctx->stream, P); }
             break;
         }
         case 3: {  // TemporalReuse
@@ -555,7 +560,8 @@ int dispatchReSTIR(rt_shader sh, int kernel, int gx, int gy) {
             if ((rc = needTex(sh, kernel, "DepthBuffer", true, X, Y, P.depth))) return rc;
             if ((rc = needTex(sh, kernel, "RayHitPointsA", false, X, Y, P.hitA))) return rc;
             if ((rc = needTex(sh, kernel, "RayHitPointsB", false, X, Y, P.hitB))) return rc;
-            if (blocks) { LaunchScope ls(ctx, IK_TEMPORAL, &P); hipLaunchKernelGGL(k_temporal, dim3(blocks), dim3(256), 0, ctx->stream, P); }
+            if (!blocks) break;
+            { LaunchScope ls(ctx, IK_TEMPORAL, &P); hipLaunchKernelGGL(k_temporal, dim3(blocks), dim3(256), 0, ctx->stream, P); }
             break;
         }
         case 4: {  // TraceRays
@@ -850,6 +856,7 @@ int rt_texture_create(rt_ctx ctx, int w, int h, rt_format format, rt_texture* ou
     if (rc) return rc;
     rt_texture t = new rt_texture_s;
     t->ctx = ctx; t->w = w; t->h = h; t->format = format;
+    t->version = ctx->versionCounter++;
     t->bytes = (size_t)w * h * (format == RT_FORMAT_R32F ? 4 : 16);
     t->dev = nullptr;
     hipError_t e = hipMalloc(&t->dev, t->bytes);
@@ -887,6 +894,7 @@ int rt_texture_set_data(rt_texture t, const void* src, size_t bytes) {
     if (bytes != t->bytes) return fail(ctx, RT_ERR_INVALID_ARG, "texture upload must be %zu bytes", t->bytes);
     HIP_TRY(ctx, hipMemcpyAsync(t->dev, src, bytes, hipMemcpyHostToDevice, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    t->version = ctx->versionCounter++;
     return RT_OK;
 }
 

@@ -10,10 +10,12 @@ drv = rt.Driver(ctx, cfg, scene)
 for _ in range(3):
     drv.render_frame()
 nb = 8192 * 2
-wp = ctx.create_buffer(nb * 4, 32)
-ctx.check(ctx.lib.rt_set_buffer(drv.shader("rt"), 0, b"WaveProfile", wp), "bind")
+which = int(os.environ.get("RT_WAVE_PROFILE_KERNEL", "0"))
+wp = ctx.create_buffer(nb * 8 + 64, 32)
+ctx.check(ctx.lib.rt_set_buffer(drv.shader("rt"), 4 if which == 2 else 0, b"WaveProfile", wp), "bind")
 drv.update_per_frame()
-drv.run_stage(0)
+for st in range(4):
+    drv.run_stage(st)
 ctx.sync()
 a = ctx.get_buffer(wp, np.dtype([("t0", "<u8"), ("t1", "<u8"), ("mx", "<u8"), ("sm", "<u8")]))
 a = a[a["t1"] > 0]
