@@ -48,7 +48,7 @@ def native_lib():
     """librtnative.so.  Raises if it has not been built: there is no fallback implementation."""
     global _native
     if _native is None:
-        path = os.path.join(_HERE, "librtnative.so")
+        path = os.environ.get("RT_NATIVE_LIB") or os.path.join(_HERE, "librtnative.so")  # override: kernel experiments
         if not os.path.exists(path):
             raise NativeError(f"{path} is missing: build it with `make native` (no CPU fallback exists)")
         lib = C.CDLL(path, mode=C.RTLD_GLOBAL)

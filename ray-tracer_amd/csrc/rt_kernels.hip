@@ -23,6 +23,13 @@ namespace rtn {
 constexpr float PI_F = 3.1415926f;        // Constants.hlsl:3
 constexpr uint32_t MAX_BVH_DEPTH = 32;    // Constants.hlsl:14
 constexpr int WAVES_PER_BLOCK = 4;
+#ifndef RT_LEAF_NUM
+#define RT_LEAF_NUM 1
+#define RT_LEAF_DEN 2
+#endif
+#ifndef RT_MIN_WAVES
+#define RT_MIN_WAVES 1
+#endif
 #ifndef RT_TRAVERSE_V
 #define RT_TRAVERSE_V 2
 #endif
@@ -425,7 +432,7 @@ DEV void traverse2(const KParams& P, const v3 wpos, const v3 wdir, const v3 winv
             }
             // leave the phase early once at least half of the lanes still at work are waiting with a leaf
             const unsigned long long leafMask = __builtin_amdgcn_ballot_w64(alive && (e & (ENTRY_LEAF | ENTRY_LEAF_INDIRECT)) != 0);
-            if (2 * __builtin_popcountll(leafMask) >= __builtin_popcountll(__builtin_amdgcn_ballot_w64(alive))) break;
+            if (RT_LEAF_DEN * __builtin_popcountll(leafMask) >= RT_LEAF_NUM * __builtin_popcountll(__builtin_amdgcn_ballot_w64(alive))) break;
         }
         // ---------- leaf phase ----------
         if (alive && (e & (ENTRY_LEAF | ENTRY_LEAF_INDIRECT)) != 0) {
@@ -591,7 +598,7 @@ DEV v2 GetLastUV(const KParams& P, v3 worldFocalPos) {  // RS:451-461
 // InitialTrace, first half (RS:463-491,496-509): camera ray, closest hit, G-buffer outputs.
 // =====================================================================================================
 template <bool INSTR>
-__global__ __launch_bounds__(256) void k_primary(const KParams P) {
+__global__ __launch_bounds__(256, RT_MIN_WAVES) void k_primary(const KParams P) {
     extern __shared__ uint32_t lds[];
     const Pixel px = pixelOfThread(P);
     uint32_t rays = 0;
@@ -691,7 +698,7 @@ DEV v2 GenerateCandidateWeight(const KParams& P, float sqrDst, float hitAngleDot
 }
 
 template <bool INSTR>
-__global__ __launch_bounds__(256) void k_candidates(const KParams P) {
+__global__ __launch_bounds__(256, RT_MIN_WAVES) void k_candidates(const KParams P) {
     extern __shared__ uint32_t lds[];
     const Pixel px = pixelOfThread(P);
     uint32_t rays = 0;
@@ -882,7 +889,7 @@ DEV v3 SampleEnvironmentMap(const KParams& P, v3 dir) {  // RS:102-117
 }
 
 template <bool INSTR>
-__global__ __launch_bounds__(256) void k_trace_rays(const KParams P) {
+__global__ __launch_bounds__(256, 5) void k_trace_rays(const KParams P) {
     extern __shared__ uint32_t lds[];
     const Pixel px = pixelOfThread(P);
     uint32_t rays = 0, pops = 0, bvc = 0, objv = 0, trii = 0, tric = 0, iters = 0;
