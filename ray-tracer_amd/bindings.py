@@ -150,6 +150,7 @@ def host_lib():
             "rth_main_last_error": (cs, [vp]), "rth_main_render_frame": (ci, [vp]),
             "rth_main_update_per_frame": (ci, [vp]), "rth_main_run_restir_shader": (ci, [vp]),
             "rth_main_run_post_processing": (ci, [vp]), "rth_main_run_stage": (ci, [vp, ci]),
+            "rth_main_run_spatial_pass": (ci, [vp, ci]), "rth_main_run_transfer": (ci, [vp]),
             "rth_main_frame_count": (ci, [vp]), "rth_main_buffer": (vp, [vp, cs]), "rth_main_texture": (vp, [vp, cs]),
             "rth_main_shader": (vp, [vp, cs]),
         }
@@ -386,6 +387,12 @@ class Driver:
 
     def run_stage(self, stage):
         self._check(self.lib.rth_main_run_stage(self.h, stage), f"run_stage({stage})")
+
+    def run_spatial_pass(self, i):
+        self._check(self.lib.rth_main_run_spatial_pass(self.h, i), f"run_spatial_pass({i})")
+
+    def run_transfer(self):
+        self._check(self.lib.rth_main_run_transfer(self.h), "run_transfer")
 
     def run_post_processing(self):
         self._check(self.lib.rth_main_run_post_processing(self.h), "run_post_processing")

@@ -920,6 +920,10 @@ void rt_texture_release(rt_texture t) {
 
 int rt_enable_stats(rt_ctx ctx, int level) {
     if (!ctx || level < 0 || level > 2) return RT_ERR_INVALID_ARG;
+    int rc = useDevice(ctx);
+    if (rc) return rc;
+    if (level != ctx->statsLevel)  // counters restart whenever the level changes
+        HIP_TRY(ctx, hipMemsetAsync(ctx->statsDev, 0, IK_COUNT * STAT_SHARDS * 8 * sizeof(unsigned long long), ctx->stream));
     ctx->statsLevel = level;
     return RT_OK;
 }

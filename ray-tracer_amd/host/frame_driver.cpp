@@ -285,6 +285,18 @@ struct rth_main_s {
         }
         if (reuseBufferCycle == true) ComputeHelper::DispatchKernel(rtShader, "TransferToOriginal", Resolution(), RayTracerThreadSize);
     }
+    // One iteration of the loop in SpatialReuse() (Main.cs:390-399), and the copy-back after it (:401).  Split out so
+    // a multi-GPU host can exchange reservoir halos between passes.
+    void SpatialReusePass(int i) {
+        bool reuseBufferCycle = (i % 2) == 0;
+        int maxOffset = (int)(float)pow(3.0, (double)i) * cfg.SpatialReuseBlur;
+        rtShader.SetInt("MaxOffset", maxOffset);
+        rtShader.SetBool("ReuseBufferCycle", reuseBufferCycle);
+        ComputeHelper::DispatchKernel(rtShader, "SpatialReusePass", Resolution(), RayTracerThreadSize);
+    }
+    void TransferIfNeeded() {
+        if (cfg.SpatialReuseIterations % 2 == 1) ComputeHelper::DispatchKernel(rtShader, "TransferToOriginal", Resolution(), RayTracerThreadSize);
+    }
     // Main.cs:404-415
     void RunReSTIRShader() {
         CreateTextures();
@@ -409,6 +421,8 @@ int rth_main_update_per_frame(rth_main m) { return guarded(m, [&] { m->UpdatePer
 int rth_main_run_restir_shader(rth_main m) { return guarded(m, [&] { m->RunReSTIRShader(); }); }
 int rth_main_run_post_processing(rth_main m) { return guarded(m, [&] { m->RunPostProcessingShader(); }); }
 int rth_main_run_stage(rth_main m, int stage) { return guarded(m, [&] { m->RunStage(stage); }); }
+int rth_main_run_spatial_pass(rth_main m, int i) { return guarded(m, [&] { m->CreateTextures(); m->SpatialReusePass(i); }); }
+int rth_main_run_transfer(rth_main m) { return guarded(m, [&] { m->CreateTextures(); m->TransferIfNeeded(); }); }
 int rth_main_render_frame(rth_main m) {
     return guarded(m, [&] {
         m->UpdatePerFrame();

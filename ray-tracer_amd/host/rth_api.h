@@ -125,6 +125,10 @@ int rth_main_run_post_processing(rth_main m);
 /* Individual dispatches of RunReSTIRShader, for per-kernel parity tests and timing. stage: 0 InitialTrace,
  * 1 TemporalReuse, 2 SpatialReuse (all passes + transfer), 3 TraceRays. */
 int rth_main_run_stage(rth_main m, int stage);
+/* Spatial pass i alone (MaxOffset = 3^i * SpatialReuseBlur, ReuseBufferCycle = i even), and the TransferToOriginal
+ * that follows an odd number of passes: a multi-GPU host exchanges reservoir halos between these. */
+int rth_main_run_spatial_pass(rth_main m, int i);
+int rth_main_run_transfer(rth_main m);
 int rth_main_frame_count(rth_main m);
 
 /* Named access to the driver's buffers and textures ("Candidates", "CandidatesB", "TemporalFrameBuffer",

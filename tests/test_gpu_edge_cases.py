@@ -1,0 +1,157 @@
+"""Edge cases of the path, GPU vs oracle bit for bit, and the error behaviour of the C-ABI."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import harness as h
+
+rt = h.rt
+pytestmark = pytest.mark.gpu
+
+BUFS = ("HitInfos", "Candidates", "CandidatesB", "TemporalFrameBuffer")
+TEXS = ("DepthBuffer", "NormalsBuffer", "DebugOverlay", "RayHitPointsA", "RayHitPointsB", "Result", "AccumulatedResult")
+
+
+def run_and_compare(ctx, scene, cfg, frames=3):
+    drv = rt.Driver(ctx, cfg, scene)
+    orc = h.OracleRenderer(scene.arrays(), cfg, records=False)
+    try:
+        for f in range(frames):
+            drv.render_frame()
+            orc.render_frame()
+            ctx.sync()
+            for n in BUFS:
+                assert np.array_equal(h.bits(drv.buffer(n)), h.bits(orc.buf[n])), (f, n)
+            for n in TEXS:
+                assert np.array_equal(h.bits(drv.texture(n)), h.bits(orc.tex[n])), (f, n)
+        return orc
+    finally:
+        drv.close()
+
+
+@pytest.mark.parametrize("res", [(1, 1), (8, 8), (9, 7), (17, 33), (130, 5)])
+def test_tiny_and_ragged_resolutions(gpu_ctx, scene_small, res):
+    run_and_compare(gpu_ctx, scene_small, h.small_config(*res))
+
+
+def test_everything_misses(gpu_ctx, scene_small):
+    """Camera turned away from the scene: every primary ray misses, no reservoir is ever written."""
+    cfg = h.small_config(64, 40)
+    cfg.cameraRotation[0], cfg.cameraRotation[1], cfg.cameraRotation[2], cfg.cameraRotation[3] = 0.0, 0.8571673, 0.0, 0.5150381
+    orc = run_and_compare(gpu_ctx, scene_small, cfg)
+    assert not np.isfinite(orc.tex["DepthBuffer"]).any()
+    assert not orc.buf["Candidates"].view(np.uint8).any()
+
+
+@pytest.mark.parametrize("iters", [0, 1, 2, 4])
+def test_spatial_iteration_counts(gpu_ctx, scene_small, iters):
+    """Odd counts end in CandidatesB and need TransferToOriginal, even counts do not (Main.cs:387-402)."""
+    cfg = h.small_config(72, 56)
+    cfg.SpatialReuseIterations = iters
+    run_and_compare(gpu_ctx, scene_small, cfg)
+
+
+@pytest.mark.parametrize("bounces", [0, 2, 3])
+def test_bounce_counts(gpu_ctx, scene_small, bounces):
+    """MaxBounceCount other than the designed 1: no light ray at all (0), or further bounces that keep the stale
+    inverse direction of the first (2, 3) exactly as the reference's Trace loop does."""
+    cfg = h.small_config(64, 48)
+    cfg.MaxBounceCount = bounces
+    run_and_compare(gpu_ctx, scene_small, cfg)
+
+
+def test_no_temporal_reuse_and_many_candidates(gpu_ctx, scene_small):
+    cfg = h.small_config(64, 48)
+    cfg.TemporalReuseWeight = 0.0
+    cfg.TriReservoirTestsNum = 32          # the "32 candidates" configuration
+    cfg.SceneObjectReservoirTestsNum = 5
+    cfg.TemporalCandidatesNum = 3
+    cfg.SpatialReuseBlur = 40              # neighbourhood larger than the image: most offsets fall outside
+    run_and_compare(gpu_ctx, scene_small, cfg)
+
+
+def test_tight_thresholds_reject_neighbours(gpu_ctx, scene_small):
+    cfg = h.small_config(96, 64)
+    cfg.SpatialHitPointDiffThreshold = 0.05
+    cfg.SpatialNormalsAngleThreshold = 10.0
+    cfg.SpatialBRDFThreshold = 0.5
+    cfg.PixelMovementThreshold = 0.0
+    run_and_compare(gpu_ctx, scene_small, cfg)
+
+
+def test_defocus_and_moved_camera(gpu_ctx, scene_small):
+    cfg = h.small_config(64, 64)
+    cfg.DefocusStrength = 0.05
+    cfg.FocalPlaneFactor = 6.0
+    cfg.cameraPosition[0], cfg.cameraPosition[1], cfg.cameraPosition[2] = 6.0, 4.0, 3.0
+    run_and_compare(gpu_ctx, scene_small, cfg)
+
+
+def test_many_objects_deep_scene_bvh(gpu_ctx):
+    """A scene BVH with several levels, instanced meshes and several lights."""
+    scene = rt.build_scene_instanced(grid=(4, 3), emissive_objects=3, emissive_tris=24, unique=False, subdivide=False)
+    cfg = h.small_config(96, 64)
+    cfg.cameraPosition[0], cfg.cameraPosition[1], cfg.cameraPosition[2] = -4.0, 6.0, -25.0
+    cfg.cameraRotation[0], cfg.cameraRotation[1], cfg.cameraRotation[2], cfg.cameraRotation[3] = 0.0, 0.0, 0.0, 1.0
+    orc = run_and_compare(gpu_ctx, scene, cfg)
+    assert np.isfinite(orc.tex["DepthBuffer"]).sum() > 200
+
+
+# ---------------------------------------------------------------- error behaviour of the C-ABI
+def test_unbound_and_invalid_arguments(gpu_ctx):
+    lib = gpu_ctx.lib
+    sh = gpu_ctx.open_shader("ReSTIR_BVH_RayTracer")
+    try:
+        assert lib.rt_find_kernel(sh, b"InitialTrace") == 0 and lib.rt_find_kernel(sh, b"TraceRays") == 4
+        assert lib.rt_find_kernel(sh, b"NoSuchKernel") < 0
+        assert lib.rt_dispatch(sh, 0, 8, 8, 1) == -4            # RT_ERR_UNBOUND: Resolution not set
+        res = (C.c_int * 2)(64, 64)
+        lib.rt_set_ints(sh, b"Resolution", res, 2)
+        assert lib.rt_dispatch(sh, 0, 8, 8, 1) == -4            # scene buffers not bound
+        assert b"BVs" in lib.rt_last_error(gpu_ctx.h)
+        assert lib.rt_dispatch(sh, 0, 4, 8, 1) == -1            # groups do not cover the resolution
+        assert lib.rt_dispatch(sh, 7, 8, 8, 1) < 0
+        assert lib.rt_set_int(sh, b"SomethingTheShaderDoesNotDeclare", 3) == 0   # ignored, like Unity
+        assert lib.rt_enable_keyword(sh, b"NOT_A_KEYWORD") == 0
+        h_ = C.c_void_p()
+        assert lib.rt_buffer_create(gpu_ctx.h, 0, 52, C.byref(h_)) < 0
+        assert lib.rt_buffer_create(gpu_ctx.h, 4, 3, C.byref(h_)) < 0
+        assert lib.rt_shader_open(gpu_ctx.h, b"Nope", C.byref(h_)) < 0
+    finally:
+        lib.rt_shader_close(sh)
+
+
+def test_bad_scene_is_rejected(gpu_ctx, scene_small):
+    """A BVH child index beyond the buffer must be refused on the host, never handed to a kernel."""
+    a = scene_small.arrays()
+    bad = a["BVs"].copy()
+    root = a["sceneBVHStartIndex"]
+    bad["indexB"][root] = -(len(bad) + 5)
+    cfg = h.small_config(32, 32)
+    drv = rt.Driver(gpu_ctx, cfg, scene_small)
+    try:
+        gpu_ctx.set_buffer_data(drv.buffer_handle("BVs"), bad)
+        with pytest.raises(rt.NativeError, match="BVH"):
+            drv.render_frame()
+        gpu_ctx.set_buffer_data(drv.buffer_handle("BVs"), a["BVs"])
+        drv.render_frame()                                        # and recovers once the data is valid again
+        gpu_ctx.sync()
+    finally:
+        drv.close()
+
+
+def test_buffer_roundtrip_keeps_abi_layout(gpu_ctx, scene_small):
+    """Reservoir buffers live as planes inside the library; set_data/get_data always speak the 52-byte records."""
+    cfg = h.small_config(16, 16)
+    drv = rt.Driver(gpu_ctx, cfg, scene_small)
+    try:
+        drv.render_frame()
+        rng = np.random.default_rng(3)
+        data = rng.standard_normal((256, 13)).astype(np.float32).view(rt.DTYPES["Reservoir"]).reshape(-1)
+        gpu_ctx.set_buffer_data(drv.buffer_handle("CandidatesB"), data)
+        assert np.array_equal(h.bits(drv.buffer("CandidatesB")), h.bits(data))
+        drv.render_frame()                                        # converts back to planes on the next dispatch
+        gpu_ctx.sync()
+    finally:
+        drv.close()
