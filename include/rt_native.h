@@ -132,6 +132,21 @@ int rt_texture_set_data(rt_texture tex, const void* src, size_t bytes);
 int rt_texture_get_data(rt_texture tex, void* dst, size_t bytes);
 void rt_texture_release(rt_texture tex);
 
+/* ---- multi-GPU row access (no counterpart in the reference) ----------------------------------------------- */
+
+/* Device memory holding image rows [row0, row1) of a per-pixel buffer (`width` records per row) or of a texture,
+ * in the layout the library currently keeps it in: a 52-byte-record buffer is either one contiguous run (record
+ * layout) or four runs (plane layout).  A multi-GPU host maps the border rows of the reservoir buffers and of
+ * DepthBuffer right before each exchange and sends/receives them between the per-GPU processes (RCCL); row r of
+ * one process's buffer corresponds to row r of every other's, because each process keeps full-frame buffers and
+ * only renders its band.  The pointers are valid until the next call that uploads to or releases the object. */
+typedef struct {
+    void* ptr;
+    size_t bytes;
+} rt_segment;
+int rt_buffer_map_rows(rt_buffer buf, int width, int row0, int row1, rt_segment out[4], int* count);
+int rt_texture_map_rows(rt_texture tex, int row0, int row1, rt_segment* out);
+
 /* ---- measurement (no counterpart in the reference) -------------------------------------------------------- */
 
 /* Work counters of a (shader, kernel) pair, summed over every dispatch since they were last read.

@@ -69,6 +69,7 @@ def native_lib():
             "rt_texture_create": (ci, [vp, ci, ci, ci, C.POINTER(vp)]),
             "rt_texture_set_data": (ci, [vp, vp, C.c_size_t]), "rt_texture_get_data": (ci, [vp, vp, C.c_size_t]),
             "rt_texture_release": (None, [vp]),
+            "rt_buffer_map_rows": (ci, [vp, ci, ci, ci, vp, C.POINTER(ci)]), "rt_texture_map_rows": (ci, [vp, ci, ci, vp]),
             "rt_enable_stats": (ci, [vp, ci]), "rt_get_stats": (ci, [vp, ci, vp]),
             "rt_profile_enable": (ci, [vp, ci]), "rt_profile_reset": (ci, [vp]), "rt_profile_get": (ci, [vp, cs, vp]),
         }
@@ -115,6 +116,10 @@ class DispatchStats(C.Structure):
 
     def as_dict(self):
         return {n: int(getattr(self, n)) for n, _ in self._fields_}
+
+
+class Segment(C.Structure):
+    _fields_ = [("ptr", C.c_void_p), ("bytes", C.c_size_t)]
 
 
 class KernelProfile(C.Structure):
@@ -341,6 +346,17 @@ class RtContext:
         s = DispatchStats()
         self.check(self.lib.rt_get_stats(shader, kernel, C.byref(s)), "rt_get_stats")
         return s.as_dict()
+
+    def buffer_rows(self, buf, width, row0, row1):
+        """[(device pointer, bytes), ...] of image rows [row0, row1) of a per-pixel buffer (rt_buffer_map_rows)."""
+        segs, n = (Segment * 4)(), C.c_int()
+        self.check(self.lib.rt_buffer_map_rows(buf, width, row0, row1, segs, C.byref(n)), "rt_buffer_map_rows")
+        return [(segs[i].ptr, segs[i].bytes) for i in range(n.value)]
+
+    def texture_rows(self, tex, row0, row1):
+        seg = Segment()
+        self.check(self.lib.rt_texture_map_rows(tex, row0, row1, C.byref(seg)), "rt_texture_map_rows")
+        return [(seg.ptr, seg.bytes)]
 
     def profile_enable(self, timing):
         self.check(self.lib.rt_profile_enable(self.h, 1 if timing else 0), "rt_profile_enable")

@@ -918,6 +918,32 @@ void rt_texture_release(rt_texture t) {
     delete t;
 }
 
+int rt_buffer_map_rows(rt_buffer b, int width, int row0, int row1, rt_segment out[4], int* count) {
+    if (!b || !out || !count) return RT_ERR_INVALID_ARG;
+    rt_ctx ctx = b->ctx;
+    if (width < 1 || row0 < 0 || row1 < row0 || (int64_t)row1 * width > b->count)
+        return fail(ctx, RT_ERR_INVALID_ARG, "rows [%d,%d) of width %d are outside the buffer", row0, row1, width);
+    const size_t first = (size_t)row0 * width, n = (size_t)(row1 - row0) * width;
+    char* base = (char*)b->dev;
+    if (b->layout == LAYOUT_AOS) {
+        out[0].ptr = base + first * b->stride; out[0].bytes = n * b->stride;
+        *count = 1;
+    } else {
+        for (int k = 0; k < 3; k++) { out[k].ptr = base + (size_t)b->count * 16 * k + first * 16; out[k].bytes = n * 16; }
+        out[3].ptr = base + (size_t)b->count * 48 + first * 4; out[3].bytes = n * 4;
+        *count = 4;
+    }
+    return RT_OK;
+}
+int rt_texture_map_rows(rt_texture t, int row0, int row1, rt_segment* out) {
+    if (!t || !out) return RT_ERR_INVALID_ARG;
+    if (row0 < 0 || row1 < row0 || row1 > t->h) return fail(t->ctx, RT_ERR_INVALID_ARG, "rows [%d,%d) are outside the texture", row0, row1);
+    const size_t texel = t->format == RT_FORMAT_R32F ? 4 : 16;
+    out->ptr = (char*)t->dev + (size_t)row0 * t->w * texel;
+    out->bytes = (size_t)(row1 - row0) * t->w * texel;
+    return RT_OK;
+}
+
 int rt_enable_stats(rt_ctx ctx, int level) {
     if (!ctx || level < 0 || level > 2) return RT_ERR_INVALID_ARG;
     int rc = useDevice(ctx);

@@ -1,0 +1,225 @@
+"""Multi-GPU frame: the image is cut into row bands, one process and one GPU per band, the scene replicated.
+
+The reference is single-GPU; this is the sharding the path admits.  Every kernel of the frame reads only its own
+pixel, except SpatialReusePass, which gathers reservoirs and depths from up to MaxOffset rows above and below
+(plus one more row above, because a negative x offset wraps into the previous row:
+BVH_ReSTIR_DL/.../ReSTIR_BVH_RayTracer.compute:526-535).  So each process
+
+  * keeps FULL-FRAME per-pixel buffers but renders only rows [b[r], b[r+1]) (rt_set_row_band): pixel coordinates,
+    RNG seeds and buffer indices stay global, which makes the banded result bit-identical to the single-GPU one;
+  * after InitialTrace sends its border rows of DepthBuffer to its two neighbours and, before every spatial pass,
+    its border rows of that pass's source reservoir buffer (nearest-neighbour send/recv: over RCCL each transfer
+    rides one direct xGMI link);
+  * sends its band of Result and AccumulatedResult to rank 0 at the end of the frame.
+
+The schedule (which rows, which buffer, which peer) is in plain functions over a `RowStore`, so the same code runs
+over GPU memory with RCCL and, in the CPU tests, over numpy arrays with gloo.
+"""
+import torch
+import torch.distributed as dist
+
+
+def band_bounds(height, world, weights=None):
+    """Row boundaries b[0..world] of the bands, each a multiple of 8 (the tile height) except the last.
+
+    weights: optional per-row cost estimate; bands then get roughly equal cost instead of equal height."""
+    if weights is None:
+        cuts = [round(height * r / world / 8) * 8 for r in range(world)] + [height]
+    else:
+        import numpy as np
+        c = np.concatenate([[0.0], np.cumsum(np.asarray(weights, dtype=np.float64))])
+        cuts = [0]
+        for r in range(1, world):
+            row = int(np.searchsorted(c, c[-1] * r / world))
+            cuts.append(min(height, max(cuts[-1] + 8, round(row / 8) * 8)))
+        cuts.append(height)
+    for a, b in zip(cuts, cuts[1:]):
+        if b <= a:
+            raise ValueError(f"image of {height} rows cannot be cut into {world} non-empty bands of whole tiles")
+    return cuts
+
+
+def spatial_halo(max_offset):
+    """Rows a spatial pass reads beyond a band edge: offsets reach MaxOffset rows down and MaxOffset rows up, and a
+    negative x offset borrows from one row further up."""
+    return max_offset + 1
+
+
+def max_offset_of_pass(i, blur):
+    return int(3 ** i) * blur          # Main.cs:394
+
+
+class RowStore:
+    """Access to image rows of named per-pixel buffers as lists of 1-D uint8 torch tensors (memory views).
+
+    segments(..., recv=False) returns tensors to send from, recv=True tensors to receive into; commit() is called
+    once the transfers have completed (a store that stages through host memory copies the received rows back)."""
+
+    def segments(self, name, row0, row1, recv=False):
+        raise NotImplementedError
+
+    def commit(self):
+        pass
+
+
+def _exchange(store, names, rank, world, bounds, halo, height):
+    """Sends this rank's border rows of `names` to its neighbours and receives theirs, in place."""
+    ops, keep = [], []
+    for peer, mine, theirs in ((rank - 1, (bounds[rank], min(bounds[rank] + halo, bounds[rank + 1])),
+                                (max(bounds[rank] - halo, 0), bounds[rank])),
+                               (rank + 1, (max(bounds[rank + 1] - halo, bounds[rank]), bounds[rank + 1]),
+                                (bounds[rank + 1], min(bounds[rank + 1] + halo, height)))):
+        if peer < 0 or peer >= world:
+            continue
+        # a halo taller than the neighbour's band would need rows of a rank further away
+        if theirs[1] - theirs[0] > bounds[peer + 1] - bounds[peer]:
+            raise ValueError(f"halo of {halo} rows exceeds the band of rank {peer}; use fewer GPUs or a larger image")
+        for name in names:
+            for t in store.segments(name, *mine):
+                ops.append(dist.P2POp(dist.isend, t, peer))
+            for t in store.segments(name, *theirs, recv=True):
+                ops.append(dist.P2POp(dist.irecv, t, peer))
+    if ops:
+        for req in dist.batch_isend_irecv(ops):
+            req.wait()
+        store.commit()
+    return len(ops)
+
+
+def _gather(store, names, rank, world, bounds, dst=0):
+    """Every rank sends its band of `names` to rank `dst`, which receives them into its own full-frame buffers."""
+    ops = []
+    if rank == dst:
+        for r in range(world):
+            if r != dst:
+                for name in names:
+                    for t in store.segments(name, bounds[r], bounds[r + 1], recv=True):
+                        ops.append(dist.P2POp(dist.irecv, t, r))
+    else:
+        for name in names:
+            for t in store.segments(name, bounds[rank], bounds[rank + 1]):
+                ops.append(dist.P2POp(dist.isend, t, dst))
+    if ops:
+        for req in dist.batch_isend_irecv(ops):
+            req.wait()
+        store.commit()
+
+
+def render_frame_banded(stages, store, rank, world, bounds, height, iterations, blur):
+    """One frame of the ReSTIR sequence on this rank's band with the exchanges in between.
+
+    `stages` provides the band-local compute: update_per_frame(), initial_trace(), temporal_reuse(),
+    spatial_pass(i), transfer(), trace_rays(), accumulate()."""
+    stages.update_per_frame()
+    stages.initial_trace()
+    if iterations > 0:
+        _exchange(store, ["DepthBuffer"], rank, world, bounds, spatial_halo(max_offset_of_pass(iterations - 1, blur)), height)
+    stages.temporal_reuse()
+    for i in range(iterations):
+        src = "Candidates" if i % 2 == 0 else "CandidatesB"       # ReuseBufferCycle (Main.cs:392-396)
+        _exchange(store, [src], rank, world, bounds, spatial_halo(max_offset_of_pass(i, blur)), height)
+        stages.spatial_pass(i)
+    stages.transfer()
+    stages.trace_rays()
+    stages.accumulate()
+    _gather(store, ["Result", "AccumulatedResult"], rank, world, bounds)
+
+
+# ------------------------------------------------------------------------------------------------- GPU side
+class _DevicePtr:
+    def __init__(self, ptr, nbytes):
+        self.__cuda_array_interface__ = {"shape": (nbytes,), "typestr": "|u1", "data": (ptr, False), "version": 3}
+
+
+class GpuRowStore(RowStore):
+    """Rows of the driver's buffers and textures as torch tensors aliasing the library's device memory."""
+
+    BUFFERS = ("Candidates", "CandidatesB", "TemporalFrameBuffer", "HitInfos")
+
+    def __init__(self, ctx, drv, device, stage_through_host=False):
+        # stage_through_host: for backends that cannot move device memory (gloo, used to rehearse the multi-process
+        # path on a single GPU); rows then travel device -> host -> peer -> host -> device.
+        self.ctx, self.drv, self.device, self.stage = ctx, drv, device, stage_through_host
+        self._pending = []
+
+    def segments(self, name, row0, row1, recv=False):
+        if row1 <= row0:
+            return []
+        if name in self.BUFFERS:
+            segs = self.ctx.buffer_rows(self.drv.buffer_handle(name), self.drv.W, row0, row1)
+        else:
+            segs = self.ctx.texture_rows(self.drv.texture_handle(name), row0, row1)
+        dev = [torch.as_tensor(_DevicePtr(p, n), device=self.device) for p, n in segs]
+        if not self.stage:
+            return dev
+        if recv:
+            host = [torch.empty(t.shape, dtype=torch.uint8) for t in dev]
+            self._pending += list(zip(host, dev))
+            return host
+        return [t.cpu() for t in dev]      # synchronising copy on the current (= the library's) stream
+
+    def commit(self):
+        for host, dev in self._pending:
+            dev.copy_(host)
+        self._pending = []
+
+
+class _DriverStages:
+    def __init__(self, drv):
+        self.drv = drv
+        self.update_per_frame = drv.update_per_frame
+        self.initial_trace = lambda: drv.run_stage(0)
+        self.temporal_reuse = lambda: drv.run_stage(1)
+        self.spatial_pass = drv.run_spatial_pass
+        self.transfer = drv.run_transfer
+        self.trace_rays = lambda: drv.run_stage(3)
+        self.accumulate = drv.run_post_processing
+
+
+class DistributedRunner:
+    """bench.py's runner for N > 1: one process per GPU, RCCL ("nccl" backend) between them."""
+
+    def __init__(self, rt, scene, cfg, rank, world, local_rank, backend="nccl", weights=None):
+        self.rank, self.world, self.cfg = rank, world, cfg
+        torch.cuda.set_device(local_rank)
+        self.device = torch.device("cuda", local_rank)
+        if not dist.is_initialized():
+            dist.init_process_group(backend=backend, rank=rank, world_size=world,
+                                    device_id=self.device if backend == "nccl" else None)
+        self.H = cfg.Resolution[1]
+        self.bounds = band_bounds(self.H, world, weights)
+        self.ctx = rt.RtContext(local_rank)
+        self.drv = rt.Driver(self.ctx, cfg, scene, self.bounds[rank], self.bounds[rank + 1])
+        self.store = GpuRowStore(self.ctx, self.drv, self.device, stage_through_host=(backend != "nccl"))
+        self.stages = _DriverStages(self.drv)
+        # torch orders its collectives against the CURRENT torch stream: make that the library's stream, so sends
+        # wait for the kernels that produced the rows and later kernels wait for the receives, all on the GPU.
+        self.stream = torch.cuda.ExternalStream(self.ctx.stream(), device=self.device)
+
+    def render_frame(self):
+        with torch.cuda.stream(self.stream):
+            render_frame_banded(self.stages, self.store, self.rank, self.world, self.bounds, self.H,
+                                self.cfg.SpatialReuseIterations, self.cfg.SpatialReuseBlur)
+
+    def sync(self):
+        self.ctx.sync()
+        torch.cuda.synchronize(self.device)
+
+    def barrier(self):
+        dist.barrier()
+
+    def reduce(self, dt, rays):
+        t = torch.tensor([dt], dtype=torch.float64, device=self.device)
+        r = torch.tensor([rays], dtype=torch.float64, device=self.device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dist.all_reduce(r, op=dist.ReduceOp.SUM)
+        return float(t.item()), float(r.item())
+
+    def band_pixels(self):
+        return (self.bounds[self.rank + 1] - self.bounds[self.rank]) * self.cfg.Resolution[0]
+
+    def close(self):
+        self.drv.close()
+        self.ctx.close()
+        if dist.is_initialized():
+            dist.destroy_process_group()

@@ -1,0 +1,112 @@
+"""The multi-GPU schedule (row bands, halo exchange before every spatial pass, frame-buffer gather) on the CPU:
+world_size 2 and 3 over gloo, with the CPU oracle doing each rank's band.  The banded result must equal the
+single-process full-frame result bit for bit, which is the property the GPU path relies on."""
+import importlib
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+class NumpyRowStore:
+    def __init__(self, orc):
+        self.orc = orc
+
+    def segments(self, name, row0, row1, recv=False):
+        if row1 <= row0:
+            return []
+        W = self.orc.W
+        if name in self.orc.buf:
+            flat = torch.from_numpy(self.orc.buf[name].view(np.uint8))
+            return [flat[row0 * W * 52: row1 * W * 52]]
+        a = self.orc.tex[name]
+        flat = torch.from_numpy(a.reshape(-1).view(np.uint8))
+        texel = a.itemsize * (a.shape[2] if a.ndim == 3 else 1)
+        return [flat[row0 * W * texel: row1 * W * texel]]
+
+
+    def commit(self):
+        pass
+
+
+class OracleStages:
+    def __init__(self, orc, iterations):
+        self.orc, self.iterations = orc, iterations
+        self.update_per_frame = orc.update_per_frame
+        self.initial_trace = orc.initial_trace
+        self.temporal_reuse = orc.temporal_reuse
+        self.trace_rays = orc.trace_rays
+        self.accumulate = orc.accumulate
+
+    def spatial_pass(self, i):
+        self.orc.spatial_pass(i, i % 2 == 0)
+
+    def transfer(self):
+        if self.iterations % 2 == 1:
+            self.orc.transfer_to_original()
+
+
+def _worker(rank, world, port, res, frames, out_dir):
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    sys.path.insert(0, ROOT)
+    import harness as h
+    mg = importlib.import_module("ray-tracer_amd.multigpu")
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    try:
+        scene = h.rt.build_scene_s0(subdivide=False, threads=1)
+        cfg = h.small_config(*res)
+        bounds = mg.band_bounds(res[1], world)
+        banded = h.OracleRenderer(scene.arrays(), cfg, threads=1, records=False, row0=bounds[rank], row1=bounds[rank + 1])
+        full = h.OracleRenderer(scene.arrays(), cfg, threads=1, records=False)
+        store, stages = NumpyRowStore(banded), OracleStages(banded, cfg.SpatialReuseIterations)
+        W = res[0]
+        for frame in range(frames):
+            mg.render_frame_banded(stages, store, rank, world, bounds, res[1], cfg.SpatialReuseIterations, cfg.SpatialReuseBlur)
+            full.render_frame()
+            lo, hi = bounds[rank] * W, bounds[rank + 1] * W
+            for name in ("HitInfos", "Candidates", "CandidatesB", "TemporalFrameBuffer"):
+                assert np.array_equal(h.bits(banded.buf[name][lo:hi]), h.bits(full.buf[name][lo:hi])), (rank, frame, name)
+            if rank == 0:   # the gathered frame buffer is complete on rank 0
+                for name in ("Result", "AccumulatedResult"):
+                    assert np.array_equal(h.bits(banded.tex[name]), h.bits(full.tex[name])), (frame, name)
+        hit = np.isfinite(full.tex["DepthBuffer"])
+        assert hit[bounds[rank]:bounds[rank + 1]].any() or world > 2
+        open(os.path.join(out_dir, f"ok{rank}"), "w").write("ok")
+    finally:
+        dist.destroy_process_group()
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+@pytest.mark.parametrize("world,res", [(2, (64, 64)), (3, (48, 96))])
+def test_banded_equals_full_frame(tmp_path, world, res):
+    mp.spawn(_worker, args=(world, _free_port(), res, 3, str(tmp_path)), nprocs=world, join=True)
+    assert all((tmp_path / f"ok{r}").exists() for r in range(world))
+
+
+def test_band_bounds_and_halo():
+    mg = importlib.import_module("ray-tracer_amd.multigpu")
+    b = mg.band_bounds(1080, 8)
+    assert b[0] == 0 and b[-1] == 1080 and all(x % 8 == 0 for x in b[:-1]) and all(y > x for x, y in zip(b, b[1:]))
+    assert mg.band_bounds(2160, 8)[1] == 272
+    with pytest.raises(ValueError):
+        mg.band_bounds(16, 4)
+    assert [mg.max_offset_of_pass(i, 3) for i in range(3)] == [3, 9, 27]      # Main.cs:394
+    assert mg.spatial_halo(27) == 28
+    w = np.zeros(1080)
+    w[400:800] = 1.0                      # all the cost in the middle rows
+    bw = mg.band_bounds(1080, 4, weights=w)
+    assert bw[1] >= 400 and bw[3] <= 800  # cost-balanced cuts fall inside the expensive region
