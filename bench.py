@@ -6,8 +6,8 @@
 One step = one frame of the reference's sequence (InitialTrace, TemporalReuse, 3 x SpatialReusePass,
 TransferToOriginal, TraceRays, AccumulateFrames) on the "80kScene*" stand-in at 1920x1080, all inputs resident in
 HBM before the timed region.  N > 1 splits the same image into N row bands, one process per GPU (launched by
-torch.distributed.run), with reservoir halos exchanged between neighbours before every spatial pass and the frame
-buffer gathered on rank 0 (strong scaling).  Rank 0 prints ONE JSON line.
+torch.distributed.run), with reservoir halos exchanged between neighbours once per frame and the displayed
+image gathered on rank 0 (strong scaling).  Rank 0 prints ONE JSON line.
 
 value = rays cast by all ranks in the K timed frames / wall time of those frames, in Mrays/s (primary + shadow +
 light rays, counted by the kernels themselves).

@@ -36,10 +36,8 @@ struct rt_ctx_s {
     int statsLevel = 0;  // 0 off, 1 rays + active pixels, 2 all counters (instrumented kernel variants)
     unsigned long long* statsDev = nullptr;  // IK_COUNT x STAT_SHARDS x 8 counters, accumulated until read
     // workgroup -> image block table of the per-pixel kernels (see buildBlockMap)
-    uint32_t* blockMapDev = nullptr;
-    size_t blockMapCap = 0;
-    unsigned blockMapN = 0;
-    int bmBx = -1, bmBy = -1, bmMode = -1;
+    struct BlockMap { int bx, by; uint32_t* dev; unsigned n; };
+    std::vector<BlockMap> blockMaps;  // one per band height in use (a multi-GPU host alternates between a few)
     // per-internal-kernel timing with HIP events on the context's stream
     bool timing = false;
     struct Timed { int kernel; hipEvent_t start, stop; };
@@ -422,21 +420,21 @@ int pixelGrid(rt_ctx ctx, KParams& P, int gx, int gy, unsigned* blocks) {
     unsigned bx = (unsigned)(P.ResX + 15) / 16, by = (unsigned)(P.row1 - bandY0 + 15) / 16;
     if (bx > 0xffffu || by > 0xffffu) return fail(ctx, RT_ERR_LIMIT, "image too large for the block table");
     static const int mode = [] { const char* e = getenv("RT_BLOCK_MAP"); return e ? atoi(e) : 2; }();
-    if ((int)bx != ctx->bmBx || (int)by != ctx->bmBy || mode != ctx->bmMode) {
-        std::vector<uint32_t> map = buildBlockMap(bx, by, mode);
-        if (map.size() > ctx->blockMapCap) {
-            HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-            if (ctx->blockMapDev) { hipError_t e = hipFree(ctx->blockMapDev); (void)e; ctx->blockMapDev = nullptr; ctx->blockMapCap = 0; }
-            HIP_TRY(ctx, hipMalloc((void**)&ctx->blockMapDev, map.size() * 4));
-            ctx->blockMapCap = map.size();
-        }
-        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));  // earlier launches may still read the old table
-        HIP_TRY(ctx, hipMemcpy(ctx->blockMapDev, map.data(), map.size() * 4, hipMemcpyHostToDevice));
-        ctx->blockMapN = (unsigned)map.size();
-        ctx->bmBx = (int)bx; ctx->bmBy = (int)by; ctx->bmMode = mode;
+    for (auto& m : ctx->blockMaps)
+        if (m.bx == (int)bx && m.by == (int)by) { P.blockMap = m.dev; *blocks = m.n; return RT_OK; }
+    if (ctx->blockMaps.size() >= 16) {  // bounded: forget the oldest table once nothing can still be reading it
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        hipError_t e = hipFree(ctx->blockMaps.front().dev);
+        (void)e;
+        ctx->blockMaps.erase(ctx->blockMaps.begin());
     }
-    P.blockMap = ctx->blockMapDev;
-    *blocks = ctx->blockMapN;
+    std::vector<uint32_t> map = buildBlockMap(bx, by, mode);
+    rt_ctx_s::BlockMap m = {(int)bx, (int)by, nullptr, (unsigned)map.size()};
+    HIP_TRY(ctx, hipMalloc((void**)&m.dev, map.size() * 4));
+    HIP_TRY(ctx, hipMemcpy(m.dev, map.data(), map.size() * 4, hipMemcpyHostToDevice));
+    ctx->blockMaps.push_back(m);
+    P.blockMap = m.dev;
+    *blocks = m.n;
     return RT_OK;
 }
 
@@ -663,7 +661,7 @@ void rt_destroy(rt_ctx ctx) {
     if (ctx->prep.btri) e = hipFree(ctx->prep.btri);
     if (ctx->prep.objRoot) e = hipFree(ctx->prep.objRoot);
     if (ctx->statsDev) e = hipFree(ctx->statsDev);
-    if (ctx->blockMapDev) e = hipFree(ctx->blockMapDev);
+    for (auto& m : ctx->blockMaps) e = hipFree(m.dev);
     for (auto& t : ctx->pending) { e = hipEventDestroy(t.start); e = hipEventDestroy(t.stop); }
     for (auto ev : ctx->freeEvents) e = hipEventDestroy(ev);
     e = hipStreamDestroy(ctx->stream);

@@ -7,10 +7,11 @@ BVH_ReSTIR_DL/.../ReSTIR_BVH_RayTracer.compute:526-535).  So each process
 
   * keeps FULL-FRAME per-pixel buffers but renders only rows [b[r], b[r+1]) (rt_set_row_band): pixel coordinates,
     RNG seeds and buffer indices stay global, which makes the banded result bit-identical to the single-GPU one;
-  * after InitialTrace sends its border rows of DepthBuffer to its two neighbours and, before every spatial pass,
-    its border rows of that pass's source reservoir buffer (nearest-neighbour send/recv: over RCCL each transfer
-    rides one direct xGMI link);
-  * sends its band of Result and AccumulatedResult to rank 0 at the end of the frame.
+  * after TemporalReuse exchanges, ONCE per frame, its border rows of DepthBuffer and of the first pass's source
+    reservoir buffer with its two neighbours (nearest-neighbour send/recv: over RCCL each transfer rides one direct
+    xGMI link), deep enough that it can run the earlier spatial passes on a slightly widened band instead of
+    exchanging again before every pass (halo_plan);
+  * sends its band of Result (the displayed image) to rank 0 at the end of the frame.
 
 The schedule (which rows, which buffer, which peer) is in plain functions over a `RowStore`, so the same code runs
 over GPU memory with RCCL and, in the CPU tests, over numpy arrays with gloo.
@@ -105,24 +106,42 @@ def _gather(store, names, rank, world, bounds, dst=0):
         store.commit()
 
 
-def render_frame_banded(stages, store, rank, world, bounds, height, iterations, blur):
-    """One frame of the ReSTIR sequence on this rank's band with the exchanges in between.
+def halo_plan(iterations, blur):
+    """Per spatial pass i: (rows it reads beyond the rows it writes, rows it must write beyond the band).
 
-    `stages` provides the band-local compute: update_per_frame(), initial_trace(), temporal_reuse(),
-    spatial_pass(i), transfer(), trace_rays(), accumulate()."""
+    All halos are exchanged ONCE, before the first pass: a rank receives enough rows of the pass-0 source that it can
+    run the earlier passes on a band widened by what the later passes will read, recomputing a few of its
+    neighbours' rows instead of waiting for them (one exchange per frame instead of one per pass).  Pass i is run on
+    band +- extend[i], with extend[i] = sum of the halos of the passes after it."""
+    halos = [spatial_halo(max_offset_of_pass(i, blur)) for i in range(iterations)]
+    extend = [sum(halos[i + 1:]) for i in range(iterations)]
+    return halos, extend, sum(halos)
+
+
+def render_frame_banded(stages, store, rank, world, bounds, height, iterations, blur):
+    """One frame of the ReSTIR sequence on this rank's band, one halo exchange and one gather.
+
+    `stages` provides the compute: update_per_frame(), set_rows(r0, r1), initial_trace(), temporal_reuse(),
+    spatial_pass(i), transfer(), trace_rays(), accumulate(); they act on the rows last given to set_rows."""
+    b0, b1 = bounds[rank], bounds[rank + 1]
+    stages.set_rows(b0, b1)
     stages.update_per_frame()
     stages.initial_trace()
-    if iterations > 0:
-        _exchange(store, ["DepthBuffer"], rank, world, bounds, spatial_halo(max_offset_of_pass(iterations - 1, blur)), height)
     stages.temporal_reuse()
-    for i in range(iterations):
-        src = "Candidates" if i % 2 == 0 else "CandidatesB"       # ReuseBufferCycle (Main.cs:392-396)
-        _exchange(store, [src], rank, world, bounds, spatial_halo(max_offset_of_pass(i, blur)), height)
-        stages.spatial_pass(i)
+    if iterations > 0:
+        _, extend, total = halo_plan(iterations, blur)
+        _exchange(store, ["DepthBuffer", "Candidates"], rank, world, bounds, total, height)
+        for i in range(iterations):
+            # never widen past the image, nor past the rows whose inputs were received
+            lo = b0 - extend[i] if rank > 0 else b0
+            hi = b1 + extend[i] if rank < world - 1 else b1
+            stages.set_rows(max(lo, 0), min(hi, height))
+            stages.spatial_pass(i)
+        stages.set_rows(b0, b1)
     stages.transfer()
     stages.trace_rays()
     stages.accumulate()
-    _gather(store, ["Result", "AccumulatedResult"], rank, world, bounds)
+    _gather(store, ["Result"], rank, world, bounds)   # the displayed image; the running sum stays per band
 
 
 # ------------------------------------------------------------------------------------------------- GPU side
@@ -141,6 +160,7 @@ class GpuRowStore(RowStore):
         # path on a single GPU); rows then travel device -> host -> peer -> host -> device.
         self.ctx, self.drv, self.device, self.stage = ctx, drv, device, stage_through_host
         self._pending = []
+        self._views = {}
 
     def segments(self, name, row0, row1, recv=False):
         if row1 <= row0:
@@ -149,7 +169,12 @@ class GpuRowStore(RowStore):
             segs = self.ctx.buffer_rows(self.drv.buffer_handle(name), self.drv.W, row0, row1)
         else:
             segs = self.ctx.texture_rows(self.drv.texture_handle(name), row0, row1)
-        dev = [torch.as_tensor(_DevicePtr(p, n), device=self.device) for p, n in segs]
+        dev = []
+        for p, n in segs:      # the tensors only alias memory: build each once (pointers move only on re-upload)
+            t = self._views.get((p, n))
+            if t is None:
+                t = self._views[(p, n)] = torch.as_tensor(_DevicePtr(p, n), device=self.device)
+            dev.append(t)
         if not self.stage:
             return dev
         if recv:
@@ -165,8 +190,9 @@ class GpuRowStore(RowStore):
 
 
 class _DriverStages:
-    def __init__(self, drv):
+    def __init__(self, ctx, drv):
         self.drv = drv
+        self.set_rows = ctx.set_row_band
         self.update_per_frame = drv.update_per_frame
         self.initial_trace = lambda: drv.run_stage(0)
         self.temporal_reuse = lambda: drv.run_stage(1)
@@ -191,7 +217,7 @@ class DistributedRunner:
         self.ctx = rt.RtContext(local_rank)
         self.drv = rt.Driver(self.ctx, cfg, scene, self.bounds[rank], self.bounds[rank + 1])
         self.store = GpuRowStore(self.ctx, self.drv, self.device, stage_through_host=(backend != "nccl"))
-        self.stages = _DriverStages(self.drv)
+        self.stages = _DriverStages(self.ctx, self.drv)
         # torch orders its collectives against the CURRENT torch stream: make that the library's stream, so sends
         # wait for the kernels that produced the rows and later kernels wait for the receives, all on the GPU.
         self.stream = torch.cuda.ExternalStream(self.ctx.stream(), device=self.device)

@@ -1,4 +1,5 @@
-"""The multi-GPU schedule (row bands, halo exchange before every spatial pass, frame-buffer gather) on the CPU:
+"""The multi-GPU schedule (row bands, one halo exchange per frame, widened early spatial passes, frame-buffer
+gather) on the CPU:
 world_size 2 and 3 over gloo, with the CPU oracle doing each rank's band.  The banded result must equal the
 single-process full-frame result bit for bit, which is the property the GPU path relies on."""
 import importlib
@@ -40,6 +41,7 @@ class OracleStages:
     def __init__(self, orc, iterations):
         self.orc, self.iterations = orc, iterations
         self.update_per_frame = orc.update_per_frame
+        self.set_rows = orc.set_band
         self.initial_trace = orc.initial_trace
         self.temporal_reuse = orc.temporal_reuse
         self.trace_rays = orc.trace_rays
@@ -73,11 +75,12 @@ def _worker(rank, world, port, res, frames, out_dir):
             lo, hi = bounds[rank] * W, bounds[rank + 1] * W
             for name in ("HitInfos", "Candidates", "CandidatesB", "TemporalFrameBuffer"):
                 assert np.array_equal(h.bits(banded.buf[name][lo:hi]), h.bits(full.buf[name][lo:hi])), (rank, frame, name)
-            if rank == 0:   # the gathered frame buffer is complete on rank 0
-                for name in ("Result", "AccumulatedResult"):
-                    assert np.array_equal(h.bits(banded.tex[name]), h.bits(full.tex[name])), (frame, name)
+            r0, r1 = bounds[rank], bounds[rank + 1]
+            assert np.array_equal(h.bits(banded.tex["AccumulatedResult"][r0:r1]), h.bits(full.tex["AccumulatedResult"][r0:r1]))
+            if rank == 0:   # the gathered image is complete on rank 0
+                assert np.array_equal(h.bits(banded.tex["Result"]), h.bits(full.tex["Result"])), frame
         hit = np.isfinite(full.tex["DepthBuffer"])
-        assert hit[bounds[rank]:bounds[rank + 1]].any() or world > 2
+        assert hit.any() and not hit.all()      # the image has both geometry and sky
         open(os.path.join(out_dir, f"ok{rank}"), "w").write("ok")
     finally:
         dist.destroy_process_group()
@@ -91,7 +94,7 @@ def _free_port():
     return port
 
 
-@pytest.mark.parametrize("world,res", [(2, (64, 64)), (3, (48, 96))])
+@pytest.mark.parametrize("world,res", [(2, (64, 96)), (3, (48, 144))])
 def test_banded_equals_full_frame(tmp_path, world, res):
     mp.spawn(_worker, args=(world, _free_port(), res, 3, str(tmp_path)), nprocs=world, join=True)
     assert all((tmp_path / f"ok{r}").exists() for r in range(world))
@@ -106,6 +109,7 @@ def test_band_bounds_and_halo():
         mg.band_bounds(16, 4)
     assert [mg.max_offset_of_pass(i, 3) for i in range(3)] == [3, 9, 27]      # Main.cs:394
     assert mg.spatial_halo(27) == 28
+    assert mg.halo_plan(3, 3) == ([4, 10, 28], [38, 28, 0], 42)
     w = np.zeros(1080)
     w[400:800] = 1.0                      # all the cost in the middle rows
     bw = mg.band_bounds(1080, 4, weights=w)
