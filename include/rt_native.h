@@ -64,7 +64,11 @@ int rt_set_row_band(rt_ctx ctx, int row0, int row1);
 
 /* ---- shaders: the ComputeShader assets referenced by Main.cs:46-48 --------------------------------------- */
 
-/* name is one of "ReSTIR_BVH_RayTracer", "RIS_BVH_RayTracer", "PreCalc", "PostProcessor". */
+/* name is one of "ReSTIR_BVH_RayTracer", "PreCalc", "PostProcessor" (the ReSTIR project's three assets) or
+ * "RIS_BVH_RayTracer", "PreCalc", "PostProcesser" (the RIS project's: BVH_RIS_DL/Assets/Scripts/Main.cs:41-43,73).
+ * Both projects call their pre-calculation asset "PreCalc"; which CalcTriNormals runs is decided at dispatch by
+ * the buffers bound to it: "Tris" + "SceneObjects" (BVH_RIS_DL/.../ShaderHelper.cs:16,31) select the RIS
+ * project's world-normal variant, "Triangles" + "Vertices" (ShaderHelper.cs:26,37) the ReSTIR project's. */
 int rt_shader_open(rt_ctx ctx, const char* name, rt_shader* out);
 void rt_shader_close(rt_shader sh);
 
@@ -99,8 +103,10 @@ int rt_set_matrix(rt_shader sh, const char* name, const float values[16]);
 
 /* ComputeShader.SetBuffer(kernelIndex, name, buffer) (ShaderHelper.cs:9-72). */
 int rt_set_buffer(rt_shader sh, int kernel, const char* name, rt_buffer buf);
-/* One buffer name has no counterpart in the reference: "TraceRecords" (stride 32, one record per pixel), bound to
- * ReSTIR kernel 0 and/or 4.  While it is bound those dispatches run instrumented variants that also write, per
+/* The RIS project's shader takes "Tris" (stride 76), "BVs", "SceneObjects", "LightObjects", "Materials" (stride 32),
+ * "HitInfos" (stride 40) and "Candidates" (stride 16, float4) (BVH_RIS_DL/.../ShaderHelper.cs:7-52).
+ * One buffer name has no counterpart in the reference: "TraceRecords" (stride 32, one record per pixel), bound to
+ * ReSTIR kernel 0 and/or 4, or RIS kernel 0 and/or 1.  While it is bound those dispatches run instrumented variants that also write, per
  * pixel, 8 dwords: closest-hit triangle, scene object, BVH visit-order hash of the primary ray, selected light
  * object, selected light triangle, visit hash and closest-hit triangle of the shadow ray, visit hash of the rays
  * cast by TraceRays.  Parity tests compare them with the oracle's records. */

@@ -14,11 +14,14 @@ from .bindings import (  # noqa: F401
     MainConfig,
     Mesh,
     NativeError,
+    RisConfig,
+    RisDriver,
     RtContext,
     Scene,
     default_config,
     host_lib,
     native_lib,
+    ris_default_config,
     world_to_local,
 )
 from .scenes import build_scene_s0, build_scene_instanced, ASSET_DIR  # noqa: F401

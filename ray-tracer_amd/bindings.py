@@ -29,7 +29,15 @@ DTYPES = {
                              ("lightTri", "<i4"), ("shadowVisitHash", "<u4"), ("shadowTri", "<i4"),
                              ("bounceVisitHash", "<u4")]),
     "Int2": np.dtype([("x", "<i4"), ("y", "<i4")]),
+    # RIS project (BVH_RIS_DL)
+    "RisTri": np.dtype([("vA", "<f4", 3), ("vB", "<f4", 3), ("vC", "<f4", 3), ("uvA", "<f4", 2), ("uvB", "<f4", 2),
+                        ("uvC", "<f4", 2), ("worldNormal", "<f4", 3), ("parentIndex", "<i4")]),
+    "RisMaterial": np.dtype([("color", "<f4", 3), ("specularColor", "<f4", 3), ("brightness", "<f4"), ("smoothness", "<f4")]),
+    "RisHitInfo": np.dtype([("dst", "<f4"), ("hitPoint", "<f4", 3), ("uv", "<f4", 2), ("normal", "<f4", 3),
+                            ("materialIndex", "<i4")]),
+    "Float4": np.dtype([("x", "<f4"), ("y", "<f4"), ("z", "<f4"), ("w", "<f4")]),
 }
+assert [DTYPES[k].itemsize for k in ("RisTri", "RisMaterial", "RisHitInfo", "Float4")] == [76, 32, 40, 16]
 assert [DTYPES[k].itemsize for k in ("BV", "Triangle", "Vertex", "SceneObject", "LightObject", "Material", "HitInfo",
                                      "Reservoir", "TraceRecord")] == [32, 28, 20, 168, 80, 108, 52, 52, 32]
 
@@ -96,6 +104,22 @@ class MainConfig(C.Structure):
                 ("cameraRotation", C.c_float * 4), ("frameRandBase", C.c_uint32), ("frameRandStep", C.c_uint32)]
 
 
+class RisConfig(C.Structure):
+    """rth_ris_config (host/rth_api.h): the inspector fields of the RIS project's Main that reach the compute path."""
+    _fields_ = [("Resolution", C.c_int32 * 2), ("fieldOfView", C.c_float), ("MaxBounceCount", C.c_int32),
+                ("RaysPerPixel", C.c_int32), ("ScatterProbability", C.c_float), ("DefocusStrength", C.c_float),
+                ("FocalPlaneFactor", C.c_float), ("DebugMaxTriChecks", C.c_int32), ("DebugMaxBVChecks", C.c_int32),
+                ("SceneObjectCandidatesNum", C.c_int32), ("TriCandidatesNum", C.c_int32),
+                ("SceneObjectReservoirTestsNum", C.c_int32), ("TriReservoirTestsNum", C.c_int32),
+                ("CandidateReservoirTestsNum", C.c_int32), ("cameraPosition", C.c_float * 3),
+                ("cameraEulerDeg", C.c_float * 3), ("smoothness", C.c_float), ("frameRandBase", C.c_uint32),
+                ("frameRandStep", C.c_uint32)]
+
+
+class _RisSceneData(C.Structure):
+    _fields_ = [("Tris", C.c_void_p), ("nTris", C.c_int64), ("Materials", C.c_void_p), ("nMaterials", C.c_int64)]
+
+
 class _MaterialInput(C.Structure):
     _fields_ = [("brightness", C.c_float), ("col", C.c_float * 3), ("roughness", C.c_float),
                 ("metallicity", C.c_float), ("bump", C.c_float)]
@@ -126,7 +150,8 @@ class KernelProfile(C.Structure):
     _fields_ = [("launches", C.c_uint64), ("milliseconds", C.c_double), ("stats", DispatchStats)]
 
 
-KERNEL_NAMES = ("primary", "candidates", "temporal", "spatial", "transfer", "trace_rays", "accumulate", "calc_tri_normals")
+KERNEL_NAMES = ("primary", "candidates", "temporal", "spatial", "transfer", "trace_rays", "accumulate", "calc_tri_normals",
+                "ris_primary", "ris_candidates", "ris_trace_rays", "ris_calc_tri_normals")
 
 
 def host_lib():
@@ -158,6 +183,13 @@ def host_lib():
             "rth_main_run_spatial_pass": (ci, [vp, ci]), "rth_main_run_transfer": (ci, [vp]),
             "rth_main_frame_count": (ci, [vp]), "rth_main_buffer": (vp, [vp, cs]), "rth_main_texture": (vp, [vp, cs]),
             "rth_main_shader": (vp, [vp, cs]),
+            "rth_ris_default_config": (None, [C.POINTER(RisConfig)]), "rth_ris_camera_transform": (None, [fp, fp]),
+            "rth_ris_main_create": (vp, [vp, C.POINTER(RisConfig), vp, ci, ci]), "rth_ris_main_destroy": (None, [vp]),
+            "rth_ris_main_last_error": (cs, [vp]), "rth_ris_main_render_frame": (ci, [vp]),
+            "rth_ris_main_update_per_frame": (ci, [vp]), "rth_ris_main_run_stage": (ci, [vp, ci]),
+            "rth_ris_main_run_post_processing": (ci, [vp]), "rth_ris_main_frame_count": (ci, [vp]),
+            "rth_ris_main_scene": (ci, [vp, C.POINTER(_RisSceneData)]), "rth_ris_main_buffer": (vp, [vp, cs]),
+            "rth_ris_main_texture": (vp, [vp, cs]), "rth_ris_main_shader": (vp, [vp, cs]),
         }
         for name, (res, args) in sig.items():
             fn = getattr(lib, name)
@@ -179,6 +211,12 @@ def world_to_local(position, euler_deg, scale):
 def default_config():
     cfg = MainConfig()
     host_lib().rth_main_default_config(C.byref(cfg))
+    return cfg
+
+
+def ris_default_config():
+    cfg = RisConfig()
+    host_lib().rth_ris_default_config(C.byref(cfg))
     return cfg
 
 
@@ -441,4 +479,70 @@ class Driver:
     def close(self):
         if self.h:
             self.lib.rth_main_destroy(self.h)
+            self.h = None
+
+
+class RisDriver:
+    """rth_ris_main: the C++ restatement of the RIS project's Main.cs driving a context through the C-ABI."""
+
+    def __init__(self, ctx, cfg, scene, row0=0, row1=0):
+        self.ctx, self.cfg, self.scene = ctx, cfg, scene
+        self.lib = host_lib()
+        self.h = self.lib.rth_ris_main_create(ctx.h, C.byref(cfg), scene.h, row0, row1)
+        if not self.h:
+            raise NativeError("rth_ris_main_create failed: " + ctx.lib.rt_last_error(ctx.h).decode())
+        self.W, self.H = cfg.Resolution[0], cfg.Resolution[1]
+
+    def _check(self, rc, what):
+        if rc != 0:
+            raise NativeError(f"{what}: {self.lib.rth_ris_main_last_error(self.h).decode()}")
+
+    def render_frame(self):
+        self._check(self.lib.rth_ris_main_render_frame(self.h), "render_frame")
+
+    def update_per_frame(self):
+        self._check(self.lib.rth_ris_main_update_per_frame(self.h), "update_per_frame")
+
+    def run_stage(self, stage):
+        self._check(self.lib.rth_ris_main_run_stage(self.h, stage), f"run_stage({stage})")
+
+    def run_post_processing(self):
+        self._check(self.lib.rth_ris_main_run_post_processing(self.h), "run_post_processing")
+
+    def shader(self, name="rt"):
+        return self.lib.rth_ris_main_shader(self.h, name.encode())
+
+    def ris_arrays(self):
+        """The RIS project's triangle and material arrays as uploaded (worldNormal still zero)."""
+        d = _RisSceneData()
+        self._check(self.lib.rth_ris_main_scene(self.h, C.byref(d)), "rth_ris_main_scene")
+        out = {}
+        for key, ptr, n, dt in (("Tris", d.Tris, d.nTris, "RisTri"), ("Materials", d.Materials, d.nMaterials, "RisMaterial")):
+            raw = np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_uint8)), (int(n) * DTYPES[dt].itemsize,))
+            out[key] = raw.view(DTYPES[dt]).copy()
+        return out
+
+    def buffer_handle(self, name):
+        h = self.lib.rth_ris_main_buffer(self.h, name.encode())
+        if not h:
+            raise NativeError(f"no driver buffer named {name}")
+        return h
+
+    def texture_handle(self, name):
+        h = self.lib.rth_ris_main_texture(self.h, name.encode())
+        if not h:
+            raise NativeError(f"no driver texture named {name}")
+        return h
+
+    _BUF_DTYPE = {"Candidates": "Float4", "HitInfos": "RisHitInfo", "Tris": "RisTri", "BVs": "BV"}
+
+    def buffer(self, name):
+        return self.ctx.get_buffer(self.buffer_handle(name), DTYPES[self._BUF_DTYPE[name]])
+
+    def texture(self, name):
+        return self.ctx.get_texture(self.texture_handle(name), self.W, self.H, 4)
+
+    def close(self):
+        if self.h:
+            self.lib.rth_ris_main_destroy(self.h)
             self.h = None

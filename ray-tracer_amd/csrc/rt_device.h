@@ -90,6 +90,15 @@ struct KParams {
     float atlasDimsX, atlasDimsY, envDimsX, envDimsY;  // raw constant words reinterpreted as float
     int32_t kwVisReuse, kwWeightRecalc, kwBrdf;
     int32_t ppFrameCount;
+    // RIS project (BVH_RIS_DL .../RIS_BVH_RayTracer.compute:6-59): its own record types and constants
+    const rt_ris_tri* risTris;
+    const rt_ris_material* risMats;
+    rt_ris_hit_info* risHit; int64_t nRisHit;
+    float4* risCand; int64_t nRisCand;
+    Tex rayHitPoints;
+    int32_t RaysPerPixel, SceneObjectCandidatesNum, TriCandidatesNum, TotCandidatesNum, CandidateReservoirTestsNum;
+    int32_t risMaxBounceCount, risMaxBVHDepth, risFrameRand;
+    int32_t risSceneObjectReservoirTestsNum, risTriReservoirTestsNum, risEmittingObjectsNum;
     // band + instrumentation
     int32_t row0, row1;
     const uint32_t* blockMap;  // launch block index -> (by << 16 | bx) of the 16x16-pixel block it renders, ~0u = none

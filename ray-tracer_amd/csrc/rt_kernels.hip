@@ -231,6 +231,20 @@ DEV float RayBVIntersect(v3 pos, v3 inv, v3 bmin, v3 bmax) {  // RS:148-161
     return didHit ? (tNear > 0 ? tNear : 0.0f) : INF();
 }
 
+// The RIS project's variant (BVH_RIS_DL .../RIS_BVH_RayTracer.compute:111-124) divides by the direction instead of
+// multiplying by a stored reciprocal; the two round differently, so it is kept as written.
+DEV float RayBVIntersectDiv(v3 pos, v3 dir, v3 bmin, v3 bmax) {
+    v3 a = bmin - pos, b = bmax - pos;
+    v3 tMin = {a.x / dir.x, a.y / dir.y, a.z / dir.z};
+    v3 tMax = {b.x / dir.x, b.y / dir.y, b.z / dir.z};
+    v3 t1 = {fminf_(tMin.x, tMax.x), fminf_(tMin.y, tMax.y), fminf_(tMin.z, tMax.z)};
+    v3 t2 = {fmaxf_(tMin.x, tMax.x), fmaxf_(tMin.y, tMax.y), fmaxf_(tMin.z, tMax.z)};
+    float tNear = fmaxf_(fmaxf_(t1.x, t1.y), t1.z);
+    float tFar = fminf_(fminf_(t2.x, t2.y), t2.z);
+    bool didHit = tFar >= tNear && tFar > 0;
+    return didHit ? (tNear > 0 ? tNear : 0.0f) : INF();
+}
+
 // GetRayCollision (RS:284-291) = TraverseSceneBVH (RS:219-282) + TraverseTrisBVH (RS:163-217), as one loop over
 // one stack.  `stk` points at this lane's column of the LDS stack (entries 64 dwords apart).  Visit order, the
 // near-first push rule and the strict `<` culls are the reference's; only what is fetched per step differs.
@@ -390,7 +404,9 @@ DEV bool nextEntry(const KParams& P, const v3 wpos, const v3 wdir, const v3 winv
     return true;
 }
 
-template <bool INSTR>
+// RIS = the RIS project's traversal (RIS_BVH_RayTracer.compute:126-238): same loops, but the box test divides by
+// the direction and the leaf loop has no back-face pre-cull.
+template <bool INSTR, bool RIS = false>
 DEV void traverse2(const KParams& P, const v3 wpos, const v3 wdir, const v3 winv, uint32_t* stk, Trav& t) {
     TravState s;
     s.rpos = wpos; s.rdir = wdir; s.rinv = winv;
@@ -412,8 +428,10 @@ DEV void traverse2(const KParams& P, const v3 wpos, const v3 wdir, const v3 winv
                 if (INSTR) { t.iters++; t.hash = (t.hash ^ (0x80000000u | e)) * 16777619u; }
                 const float4* rec = P.wide + (int64_t)e * 4;
                 const float4 q0 = rec[0], q1 = rec[1], q2 = rec[2], q3 = rec[3];
-                const float dstA = RayBVIntersect(s.rpos, s.rinv, V3(q0.x, q0.y, q0.z), V3(q0.w, q1.x, q1.y));
-                const float dstB = RayBVIntersect(s.rpos, s.rinv, V3(q1.z, q1.w, q2.x), V3(q2.y, q2.z, q2.w));
+                const float dstA = RIS ? RayBVIntersectDiv(s.rpos, s.rdir, V3(q0.x, q0.y, q0.z), V3(q0.w, q1.x, q1.y))
+                                       : RayBVIntersect(s.rpos, s.rinv, V3(q0.x, q0.y, q0.z), V3(q0.w, q1.x, q1.y));
+                const float dstB = RIS ? RayBVIntersectDiv(s.rpos, s.rdir, V3(q1.z, q1.w, q2.x), V3(q2.y, q2.z, q2.w))
+                                       : RayBVIntersect(s.rpos, s.rinv, V3(q1.z, q1.w, q2.x), V3(q2.y, q2.z, q2.w));
                 t.bvChecks += 2;
                 const uint32_t eA = __float_as_uint(q3.x), eB = __float_as_uint(q3.y);
                 const bool aFirst = dstA < dstB;  // RS:204-214: the nearer child is visited first
@@ -455,9 +473,10 @@ DEV void traverse2(const KParams& P, const v3 wpos, const v3 wdir, const v3 winv
             } else {
                 for (int triIndex = start; triIndex < start + count; triIndex++) {  // RS:179-193
                     const float4* rec = P.btri + (int64_t)triIndex * 4;
-                    const float4 q3 = rec[3];
                     if (INSTR) t.triIters++;
-                    if (dot(V3(q3.x, q3.y, q3.z), s.rdir) <= 0) {
+                    bool facing = true;
+                    if (!RIS) { const float4 q3 = rec[3]; facing = dot(V3(q3.x, q3.y, q3.z), s.rdir) <= 0; }
+                    if (facing) {
                         const float4 q0 = rec[0], q1 = rec[1], q2 = rec[2];
                         v3 edgeAB = V3(q1.x, q1.y, q1.z), edgeAC = V3(q2.x, q2.y, q2.z);
                         v3 normalVector = V3(q0.w, q1.w, q2.w);

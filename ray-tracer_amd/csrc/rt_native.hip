@@ -5,6 +5,7 @@
 // word table, named buffer/texture bindings per kernel index, keyword toggles, dispatch by kernel index.
 // Everything runs on one HIP stream per context.  There is no CPU fallback anywhere in this file.
 #include "rt_kernels.hip"
+#include "rt_kernels_ris.hip"
 
 #include <cstdarg>
 #include <cstdio>
@@ -23,8 +24,10 @@ namespace {
 enum ShaderKind { SH_RESTIR = 0, SH_RIS = 1, SH_PRECALC = 2, SH_POSTPROC = 3 };
 enum BufLayout { LAYOUT_AOS = 0, LAYOUT_RESERVOIR_PLANES = 1, LAYOUT_HIT_PLANES = 2 };
 // the kernels a dispatch is made of (one ABI dispatch may launch several)
-enum InternalKernel { IK_PRIMARY = 0, IK_CANDIDATES, IK_TEMPORAL, IK_SPATIAL, IK_TRANSFER, IK_TRACE_RAYS, IK_ACCUMULATE, IK_CALC_NORMALS, IK_COUNT };
-const char* const IK_NAMES[IK_COUNT] = {"primary", "candidates", "temporal", "spatial", "transfer", "trace_rays", "accumulate", "calc_tri_normals"};
+enum InternalKernel { IK_PRIMARY = 0, IK_CANDIDATES, IK_TEMPORAL, IK_SPATIAL, IK_TRANSFER, IK_TRACE_RAYS, IK_ACCUMULATE, IK_CALC_NORMALS,
+                      IK_RIS_PRIMARY, IK_RIS_CANDIDATES, IK_RIS_TRACE_RAYS, IK_RIS_CALC_NORMALS, IK_COUNT };
+const char* const IK_NAMES[IK_COUNT] = {"primary", "candidates", "temporal", "spatial", "transfer", "trace_rays", "accumulate", "calc_tri_normals",
+                                        "ris_primary", "ris_candidates", "ris_trace_rays", "ris_calc_tri_normals"};
 
 }  // namespace
 
@@ -43,8 +46,8 @@ struct rt_ctx_s {
     struct Timed { int kernel; hipEvent_t start, stop; };
     std::vector<Timed> pending;
     std::vector<hipEvent_t> freeEvents;
-    double timeMs[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    uint64_t launches[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    double timeMs[IK_COUNT] = {};
+    uint64_t launches[IK_COUNT] = {};
     uint64_t versionCounter = 1;
     // prepared traversal data (derived from the bound scene buffers)
     struct Prep {
@@ -57,7 +60,7 @@ struct rt_ctx_s {
         uint32_t sceneRootEntry = 0;
         int stackDepth = 0;
         bool valid = false;
-    } prep;
+    } prep[2];  // [0] ReSTIR project's scene buffers, [1] RIS project's
 };
 
 struct rt_buffer_s {
@@ -213,17 +216,27 @@ int subtreeDepth(const std::vector<rt_bv>& bvs, uint32_t root, int64_t nLeafTarg
 
 // Validates the scene buffers the traversal kernels index without bounds checks and (re)builds the derived
 // device arrays: wide BVH nodes, baked triangles, per-object root entries.  Cached on the buffers' versions.
-int prepareScene(rt_shader sh, int kernel, KParams& P) {
+// `ris` selects the RIS project's buffer set: "Tris" (76-byte triangles with inline vertices), 32-byte materials, no
+// vertex buffer (BVH_RIS_DL .../ShaderHelper.cs:7-33).
+int prepareScene(rt_shader sh, int kernel, KParams& P, bool ris = false) {
     rt_ctx ctx = sh->ctx;
-    rt_buffer bBVs = boundBuffer(sh, kernel, "BVs"), bTris = boundBuffer(sh, kernel, "Triangles"),
-              bVerts = boundBuffer(sh, kernel, "Vertices"), bObjs = boundBuffer(sh, kernel, "SceneObjects"),
+    rt_buffer bBVs = boundBuffer(sh, kernel, "BVs"), bTris = boundBuffer(sh, kernel, ris ? "Tris" : "Triangles"),
+              bVerts = ris ? nullptr : boundBuffer(sh, kernel, "Vertices"), bObjs = boundBuffer(sh, kernel, "SceneObjects"),
               bMats = boundBuffer(sh, kernel, "Materials");
-    if (!bBVs || !bTris || !bVerts || !bObjs || !bMats)
-        return fail(ctx, RT_ERR_UNBOUND, "kernel %d needs BVs, Triangles, Vertices, SceneObjects and Materials bound", kernel);
-    if (bBVs->stride != 32 || bTris->stride != 28 || bVerts->stride != 20 || bObjs->stride != 168 || bMats->stride != 108)
-        return fail(ctx, RT_ERR_INVALID_ARG, "scene buffer strides must be BVs 32, Triangles 28, Vertices 20, SceneObjects 168, Materials 108");
+    if (ris) {
+        if (!bBVs || !bTris || !bObjs || !bMats)
+            return fail(ctx, RT_ERR_UNBOUND, "kernel %d needs BVs, Tris, SceneObjects and Materials bound", kernel);
+        if (bBVs->stride != 32 || bTris->stride != 76 || bObjs->stride != 168 || bMats->stride != 32)
+            return fail(ctx, RT_ERR_INVALID_ARG, "scene buffer strides must be BVs 32, Tris 76, SceneObjects 168, Materials 32");
+        bVerts = bTris;  // stands in for the absent vertex buffer in the cache key below
+    } else {
+        if (!bBVs || !bTris || !bVerts || !bObjs || !bMats)
+            return fail(ctx, RT_ERR_UNBOUND, "kernel %d needs BVs, Triangles, Vertices, SceneObjects and Materials bound", kernel);
+        if (bBVs->stride != 32 || bTris->stride != 28 || bVerts->stride != 20 || bObjs->stride != 168 || bMats->stride != 108)
+            return fail(ctx, RT_ERR_INVALID_ARG, "scene buffer strides must be BVs 32, Triangles 28, Vertices 20, SceneObjects 168, Materials 108");
+    }
     const uint32_t sceneStart = cWord(sh, "SceneBVHStartIndex");
-    auto& pr = ctx->prep;
+    auto& pr = ctx->prep[ris ? 1 : 0];
     const bool fresh = pr.valid && pr.vBVs == bBVs->version && pr.vTris == bTris->version && pr.vVerts == bVerts->version &&
                        pr.vObjs == bObjs->version && pr.pBVs == bBVs->dev && pr.pTris == bTris->dev && pr.pVerts == bVerts->dev &&
                        pr.pObjs == bObjs->dev && pr.sceneStart == sceneStart;
@@ -232,11 +245,12 @@ int prepareScene(rt_shader sh, int kernel, KParams& P) {
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
         std::vector<rt_bv> bvs((size_t)bBVs->count);
         std::vector<rt_scene_object> objs((size_t)bObjs->count);
-        std::vector<rt_triangle> tris((size_t)bTris->count);
+        std::vector<rt_triangle> tris(ris ? 0 : (size_t)bTris->count);
         HIP_TRY(ctx, hipMemcpy(bvs.data(), bBVs->dev, bvs.size() * sizeof(rt_bv), hipMemcpyDeviceToHost));
         HIP_TRY(ctx, hipMemcpy(objs.data(), bObjs->dev, objs.size() * sizeof(rt_scene_object), hipMemcpyDeviceToHost));
-        HIP_TRY(ctx, hipMemcpy(tris.data(), bTris->dev, tris.size() * sizeof(rt_triangle), hipMemcpyDeviceToHost));
+        if (!ris) HIP_TRY(ctx, hipMemcpy(tris.data(), bTris->dev, tris.size() * sizeof(rt_triangle), hipMemcpyDeviceToHost));
         if (bvs.size() >= (size_t)ENTRY_INDEX_MASK) return fail(ctx, RT_ERR_BAD_SCENE, "too many BVH nodes");
+        if (sceneStart >= bvs.size()) return fail(ctx, RT_ERR_BAD_SCENE, "SceneBVHStartIndex %u is outside the BVs buffer", sceneStart);
         for (const auto& t : tris)
             if (t.vertex0Index < 0 || t.vertex1Index < 0 || t.vertex2Index < 0 || t.vertex0Index >= bVerts->count ||
                 t.vertex1Index >= bVerts->count || t.vertex2Index >= bVerts->count)
@@ -270,8 +284,12 @@ int prepareScene(rt_shader sh, int kernel, KParams& P) {
         if ((rc = ensure((void**)&pr.objRoot, &pr.objRootBytes, (size_t)bObjs->count * 4))) return rc;
         hipLaunchKernelGGL(k_build_wide, dim3((unsigned)((bBVs->count + 255) / 256)), dim3(256), 0, ctx->stream,
                            (const rt_bv*)bBVs->dev, bBVs->count, pr.wide);
-        hipLaunchKernelGGL(k_bake_tris, dim3((unsigned)((bTris->count + 255) / 256)), dim3(256), 0, ctx->stream,
-                           (const rt_triangle*)bTris->dev, bTris->count, (const rt_vertex*)bVerts->dev, bVerts->count, pr.btri);
+        if (ris)
+            hipLaunchKernelGGL(k_ris_bake_tris, dim3((unsigned)((bTris->count + 255) / 256)), dim3(256), 0, ctx->stream,
+                               (const rt_ris_tri*)bTris->dev, bTris->count, pr.btri);
+        else
+            hipLaunchKernelGGL(k_bake_tris, dim3((unsigned)((bTris->count + 255) / 256)), dim3(256), 0, ctx->stream,
+                               (const rt_triangle*)bTris->dev, bTris->count, (const rt_vertex*)bVerts->dev, bVerts->count, pr.btri);
         hipLaunchKernelGGL(k_obj_root_entries, dim3((unsigned)((bObjs->count + 255) / 256)), dim3(256), 0, ctx->stream,
                            (const rt_bv*)bBVs->dev, bBVs->count, (const rt_scene_object*)bObjs->dev, bObjs->count, pr.objRoot);
         HIP_TRY(ctx, hipGetLastError());
@@ -292,9 +310,15 @@ int prepareScene(rt_shader sh, int kernel, KParams& P) {
     P.wide = pr.wide; P.btri = pr.btri; P.objRootEntry = pr.objRoot;
     P.BVs = (const rt_bv*)bBVs->dev; P.nBVs = bBVs->count;
     P.objs = (const rt_scene_object*)bObjs->dev; P.nObjs = bObjs->count;
-    P.tris = (const rt_triangle*)bTris->dev; P.nTris = bTris->count;
-    P.verts = (const rt_vertex*)bVerts->dev; P.nVerts = bVerts->count;
-    P.mats = (const rt_material*)bMats->dev; P.nMats = bMats->count;
+    P.nTris = bTris->count; P.nMats = bMats->count;
+    if (ris) {
+        P.risTris = (const rt_ris_tri*)bTris->dev;
+        P.risMats = (const rt_ris_material*)bMats->dev;
+    } else {
+        P.tris = (const rt_triangle*)bTris->dev;
+        P.verts = (const rt_vertex*)bVerts->dev; P.nVerts = bVerts->count;
+        P.mats = (const rt_material*)bMats->dev;
+    }
     P.sceneRootEntry = pr.sceneRootEntry;
     P.stackDepth = pr.stackDepth;
     static const bool diagNoTraverse = getenv("RT_DIAG_NO_TRAVERSE") != nullptr;  // timing experiments only: every ray misses
@@ -585,9 +609,103 @@ int dispatchReSTIR(rt_shader sh, int kernel, int gx, int gy) {
     return RT_OK;
 }
 
+// RIS_BVH_RayTracer: GenerateCandidates (0), TraceRays (1).  Bindings as BVH_RIS_DL .../ShaderHelper.cs:7-52 and
+// Main.cs:329,352,365 make them.
+int dispatchRIS(rt_shader sh, int kernel, int gx, int gy) {
+    rt_ctx ctx = sh->ctx;
+    KParams P;
+    memset(&P, 0, sizeof P);
+    fillConstants(sh, P);
+    P.RaysPerPixel = (int32_t)cWord(sh, "RaysPerPixel");
+    P.SceneObjectCandidatesNum = (int32_t)cWord(sh, "SceneObjectCandidatesNum");
+    P.TriCandidatesNum = (int32_t)cWord(sh, "TriCandidatesNum");
+    P.TotCandidatesNum = (int32_t)cWord(sh, "TotCandidatesNum");
+    P.CandidateReservoirTestsNum = (int32_t)cWord(sh, "CandidateReservoirTestsNum");
+    P.risMaxBounceCount = (int32_t)cWord(sh, "MaxBounceCount");
+    P.risMaxBVHDepth = (int32_t)cWord(sh, "MaxBVHDepth");
+    P.risFrameRand = (int32_t)cWord(sh, "FrameRand");
+    P.risSceneObjectReservoirTestsNum = (int32_t)cWord(sh, "SceneObjectReservoirTestsNum");
+    P.risTriReservoirTestsNum = (int32_t)cWord(sh, "TriReservoirTestsNum");
+    P.risEmittingObjectsNum = (int32_t)cWord(sh, "EmittingObjectsNum");
+    unsigned blocks = 0;
+    int rc = pixelGrid(ctx, P, gx, gy, &blocks);
+    if (rc) return rc;
+    const int X = P.ResX, Y = P.ResY;
+    const int64_t npx = (int64_t)X * Y;
+    if (kernel != 0 && kernel != 1) return fail(ctx, RT_ERR_INVALID_ARG, "RIS_BVH_RayTracer has no kernel %d", kernel);
+    rt_buffer rec = boundBuffer(sh, kernel, "TraceRecords");
+    bool instr = ctx->statsLevel >= 2;
+    if (rec) {
+        if (rec->stride != RECORD_DWORDS * 4 || rec->count < npx) return fail(ctx, RT_ERR_INVALID_ARG, "TraceRecords must have stride 32 and one record per pixel");
+        P.records = (uint32_t*)rec->dev;
+        instr = true;
+    }
+    if (ctx->timing && ctx->pending.size() > 8192 && (rc = drainTiming(ctx))) return rc;
+    if ((rc = prepareScene(sh, kernel, P, true))) return rc;
+    rt_buffer hit = boundBuffer(sh, kernel, "HitInfos"), cand = boundBuffer(sh, kernel, "Candidates");
+    if (!hit || !cand) return fail(ctx, RT_ERR_UNBOUND, "kernel %d needs HitInfos and Candidates bound", kernel);
+    if (hit->stride != 40 || cand->stride != 16) return fail(ctx, RT_ERR_INVALID_ARG, "HitInfos stride must be 40 and Candidates 16");
+    if (P.RaysPerPixel < 1) return fail(ctx, RT_ERR_INVALID_ARG, "constant 'RaysPerPixel' must be at least 1");
+    // every pixel's own record must exist: the candidate kernel reads back what the primary-ray kernel stored
+    if (hit->count < (npx - 1) * P.RaysPerPixel + 1)
+        return fail(ctx, RT_ERR_INVALID_ARG, "HitInfos holds %lld records, Resolution x RaysPerPixel needs %lld", (long long)hit->count,
+                    (long long)((npx - 1) * P.RaysPerPixel + 1));
+    if (P.TotCandidatesNum < 0 || P.SceneObjectCandidatesNum < 0 || P.TriCandidatesNum < 0 ||
+        (npx * P.RaysPerPixel) * (int64_t)(P.TotCandidatesNum > 0 ? P.TotCandidatesNum : 1) > 0x7fffffffLL)
+        return fail(ctx, RT_ERR_LIMIT, "candidate indices would not fit the reference's 32-bit candidate index");
+    P.risHit = (rt_ris_hit_info*)hit->dev; P.nRisHit = hit->count;
+    P.risCand = (float4*)cand->dev; P.nRisCand = cand->count;
+    const size_t ldsBytes = (size_t)WAVES_PER_BLOCK * P.stackDepth * 64 * 4;
+    if (kernel == 0) {
+        rt_buffer lights = boundBuffer(sh, kernel, "LightObjects");
+        if (!lights) return fail(ctx, RT_ERR_UNBOUND, "kernel 0: buffer 'LightObjects' is not bound");
+        if (lights->stride != 80) return fail(ctx, RT_ERR_INVALID_ARG, "LightObjects stride must be 80");
+        P.lights = (const rt_light_object*)lights->dev; P.nLights = lights->count;
+        if ((rc = needTex(sh, kernel, "DebugOverlay", false, X, Y, P.debugOverlay))) return rc;
+        if ((rc = needTex(sh, kernel, "RayHitPoints", false, X, Y, P.rayHitPoints))) return rc;
+        if (!blocks) return RT_OK;
+        {
+            LaunchScope ls(ctx, IK_RIS_PRIMARY, &P);
+            if (instr) hipLaunchKernelGGL(k_ris_primary<true>, dim3(blocks), dim3(256), ldsBytes, ctx->stream, P);
+            else hipLaunchKernelGGL(k_ris_primary<false>, dim3(blocks), dim3(256), ldsBytes, ctx->stream, P);
+        }
+        {
+            LaunchScope ls(ctx, IK_RIS_CANDIDATES, &P);
+            hipLaunchKernelGGL(k_ris_candidates, dim3(blocks), dim3(256), 0, ctx->stream, P);
+        }
+    } else {
+        if ((rc = needTex(sh, kernel, "Result", false, X, Y, P.result))) return rc;
+        if (!blocks) return RT_OK;
+        LaunchScope ls(ctx, IK_RIS_TRACE_RAYS, &P);
+        if (instr) hipLaunchKernelGGL(k_ris_trace_rays<true>, dim3(blocks), dim3(256), ldsBytes, ctx->stream, P);
+        else hipLaunchKernelGGL(k_ris_trace_rays<false>, dim3(blocks), dim3(256), ldsBytes, ctx->stream, P);
+    }
+    HIP_TRY(ctx, hipGetLastError());
+    return RT_OK;
+}
+
 int dispatchPreCalc(rt_shader sh, int kernel, int gx) {
     rt_ctx ctx = sh->ctx;
     if (kernel != 0) return fail(ctx, RT_ERR_INVALID_ARG, "PreCalc has no kernel %d", kernel);
+    // Both projects name their pre-calculation shader "PreCalc"; the RIS project's binds "Tris" + "SceneObjects" and
+    // sets "TrisNum" (BVH_RIS_DL .../ShaderHelper.cs:16-18,31), the ReSTIR project's "Triangles" + "Vertices".
+    if (rt_buffer rTris = boundBuffer(sh, 0, "Tris")) {
+        rt_buffer rObjs = boundBuffer(sh, 0, "SceneObjects");
+        if (!rObjs) return fail(ctx, RT_ERR_UNBOUND, "CalcTriNormals needs Tris and SceneObjects bound");
+        if (rTris->stride != 76 || rObjs->stride != 168) return fail(ctx, RT_ERR_INVALID_ARG, "CalcTriNormals: Tris stride must be 76 and SceneObjects 168");
+        uint32_t trisNum = cWord(sh, "TrisNum");
+        if (gx <= 0) return RT_OK;
+        uint64_t covered = (uint64_t)gx * 256;
+        uint32_t n = trisNum < covered ? trisNum : (uint32_t)covered;
+        {
+            LaunchScope ls(ctx, IK_RIS_CALC_NORMALS, nullptr);
+            hipLaunchKernelGGL(k_ris_calc_tri_normals, dim3((unsigned)gx), dim3(256), 0, ctx->stream, (rt_ris_tri*)rTris->dev, rTris->count,
+                               (const rt_scene_object*)rObjs->dev, rObjs->count, n);
+        }
+        HIP_TRY(ctx, hipGetLastError());
+        rTris->version = ctx->versionCounter++;
+        return RT_OK;
+    }
     rt_buffer bTris = boundBuffer(sh, 0, "Triangles"), bVerts = boundBuffer(sh, 0, "Vertices");
     if (!bTris || !bVerts) return fail(ctx, RT_ERR_UNBOUND, "CalcTriNormals needs Triangles and Vertices bound");
     if (bTris->stride != 28 || bVerts->stride != 20) return fail(ctx, RT_ERR_INVALID_ARG, "CalcTriNormals: Triangles stride must be 28 and Vertices 20");
@@ -657,9 +775,11 @@ void rt_destroy(rt_ctx ctx) {
     if (!ctx) return;
     hipError_t e = hipSetDevice(ctx->device);
     e = hipStreamSynchronize(ctx->stream);
-    if (ctx->prep.wide) e = hipFree(ctx->prep.wide);
-    if (ctx->prep.btri) e = hipFree(ctx->prep.btri);
-    if (ctx->prep.objRoot) e = hipFree(ctx->prep.objRoot);
+    for (auto& pr : ctx->prep) {
+        if (pr.wide) e = hipFree(pr.wide);
+        if (pr.btri) e = hipFree(pr.btri);
+        if (pr.objRoot) e = hipFree(pr.objRoot);
+    }
     if (ctx->statsDev) e = hipFree(ctx->statsDev);
     for (auto& m : ctx->blockMaps) e = hipFree(m.dev);
     for (auto& t : ctx->pending) { e = hipEventDestroy(t.start); e = hipEventDestroy(t.stop); }
@@ -690,9 +810,8 @@ int rt_shader_open(rt_ctx ctx, const char* name, rt_shader* out) {
     if (!strcmp(name, "ReSTIR_BVH_RayTracer")) kind = SH_RESTIR;
     else if (!strcmp(name, "RIS_BVH_RayTracer")) kind = SH_RIS;
     else if (!strcmp(name, "PreCalc")) kind = SH_PRECALC;
-    else if (!strcmp(name, "PostProcessor")) kind = SH_POSTPROC;
+    else if (!strcmp(name, "PostProcessor") || !strcmp(name, "PostProcesser")) kind = SH_POSTPROC;  // the RIS project's file is PostProcesser.compute
     else return fail(ctx, RT_ERR_INVALID_ARG, "unknown shader '%s'", name);
-    if (kind == SH_RIS) return fail(ctx, RT_ERR_INVALID_ARG, "shader 'RIS_BVH_RayTracer' is not built into this library yet");
     rt_shader sh = new rt_shader_s;
     sh->ctx = ctx;
     sh->kind = kind;
@@ -707,6 +826,10 @@ int rt_find_kernel(rt_shader sh, const char* name) {
     switch (sh->kind) {
         case SH_RESTIR:
             for (int i = 0; i < 5; i++) if (!strcmp(name, restir[i])) return i;
+            break;
+        case SH_RIS:
+            if (!strcmp(name, "GenerateCandidates")) return 0;
+            if (!strcmp(name, "TraceRays")) return 1;
             break;
         case SH_PRECALC: if (!strcmp(name, "CalcTriNormals")) return 0; break;
         case SH_POSTPROC: if (!strcmp(name, "AccumulateFrames")) return 0; break;
@@ -724,6 +847,7 @@ int rt_dispatch(rt_shader sh, int kernel, int gx, int gy, int gz) {
     if (gx == 0 || gy == 0 || gz == 0) return RT_OK;
     switch (sh->kind) {
         case SH_RESTIR: return dispatchReSTIR(sh, kernel, gx, gy);
+        case SH_RIS: return dispatchRIS(sh, kernel, gx, gy);
         case SH_PRECALC: return dispatchPreCalc(sh, kernel, gx);
         case SH_POSTPROC: return dispatchPostProc(sh, kernel, gx, gy);
     }
@@ -981,6 +1105,11 @@ int rt_get_stats(rt_shader sh, int kernel, rt_dispatch_stats* out) {
         for (int j = 0; j < 2; j++)
             if (map[kernel][j] >= 0 && (rc = readStats(ctx, map[kernel][j], out))) return rc;
         return RT_OK;
+    }
+    if (sh->kind == SH_RIS) {
+        if (kernel == 0) { if ((rc = readStats(ctx, IK_RIS_PRIMARY, out))) return rc; return readStats(ctx, IK_RIS_CANDIDATES, out); }
+        if (kernel == 1) return readStats(ctx, IK_RIS_TRACE_RAYS, out);
+        return fail(ctx, RT_ERR_INVALID_ARG, "no kernel %d", kernel);
     }
     if (sh->kind == SH_POSTPROC && kernel == 0) return readStats(ctx, IK_ACCUMULATE, out);
     return fail(ctx, RT_ERR_INVALID_ARG, "no statistics are kept for this shader's kernel %d", kernel);

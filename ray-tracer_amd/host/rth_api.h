@@ -138,6 +138,50 @@ rt_buffer rth_main_buffer(rth_main m, const char* name);
 rt_texture rth_main_texture(rth_main m, const char* name);
 rt_shader rth_main_shader(rth_main m, const char* name); /* "rt", "pp", "pc" */
 
+/* ------------------------------------- frame driver of the RIS project ---------------------------------- */
+typedef struct rth_ris_main_s* rth_ris_main;
+
+/* The inspector fields of the RIS project's Main (BVH_RIS_DL/Assets/Scripts/Main.cs:11-38) that reach the compute
+ * path, the camera transform, and the one material input its Material2 adds (MatTypesInput2.x). */
+typedef struct {
+    int32_t Resolution[2];
+    float fieldOfView;
+    int32_t MaxBounceCount, RaysPerPixel;
+    float ScatterProbability, DefocusStrength, FocalPlaneFactor;
+    int32_t DebugMaxTriChecks, DebugMaxBVChecks;
+    int32_t SceneObjectCandidatesNum, TriCandidatesNum;
+    int32_t SceneObjectReservoirTestsNum, TriReservoirTestsNum, CandidateReservoirTestsNum;
+    float cameraPosition[3];
+    float cameraEulerDeg[3]; /* transform.rotation.eulerAngles (Main.cs:190) */
+    float smoothness;        /* Material2.smoothness of every material */
+    uint32_t frameRandBase, frameRandStep; /* as in rth_main_config */
+} rth_ris_config;
+
+/* CameraTransform as Main.SetCameraOrientationAndTransform builds it from the Euler angles (Main.cs:189-211), column-major. */
+void rth_ris_camera_transform(const float eulerDeg[3], float out[16]);
+void rth_ris_default_config(rth_ris_config* cfg); /* BVH_RIS_DL/Assets/Scenes/Ray Tracer.unity:381-426 */
+
+/* Main.Start (Main.cs:87-103) on a built scene: derives the RIS project's triangle and material arrays from it,
+ * opens RIS_BVH_RayTracer / PostProcesser / PreCalc on `ctx`, uploads everything and runs CalcTriNormals. */
+rth_ris_main rth_ris_main_create(rt_ctx ctx, const rth_ris_config* cfg, rth_scene scene, int row0, int row1);
+void rth_ris_main_destroy(rth_ris_main m);
+const char* rth_ris_main_last_error(rth_ris_main m);
+/* One frame: UpdatePerFrame (:132-144), RunRenderShader (:319-371), RunPostProcessingShader (:373-376). */
+int rth_ris_main_render_frame(rth_ris_main m);
+int rth_ris_main_update_per_frame(rth_ris_main m);
+int rth_ris_main_run_stage(rth_ris_main m, int stage); /* 0 GenerateCandidates, 1 TraceRays */
+int rth_ris_main_run_post_processing(rth_ris_main m);
+int rth_ris_main_frame_count(rth_ris_main m);
+
+typedef struct {
+    const rt_ris_tri* Tris; int64_t nTris;               /* worldNormal = 0: CalcTriNormals fills it on the device */
+    const rt_ris_material* Materials; int64_t nMaterials;
+} rth_ris_scene_data;
+int rth_ris_main_scene(rth_ris_main m, rth_ris_scene_data* out);
+rt_buffer rth_ris_main_buffer(rth_ris_main m, const char* name);   /* "Tris", "Candidates", "HitInfos", ... */
+rt_texture rth_ris_main_texture(rth_ris_main m, const char* name); /* "Result", "AccumulatedResult", "DebugOverlay", "RayHitPoints" */
+rt_shader rth_ris_main_shader(rth_ris_main m, const char* name);   /* "rt", "pp", "pc" */
+
 #ifdef __cplusplus
 }
 #endif

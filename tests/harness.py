@@ -252,3 +252,172 @@ def small_config(w=64, h=64):
 def bits(a):
     """Raw bytes of a (structured) array, for bit-exact comparison that treats NaNs and signed zeros literally."""
     return np.ascontiguousarray(a).view(np.uint8).reshape(-1)
+
+
+# ------------------------------------------------------------------------------------------------ RIS project
+class OrcRisParams(C.Structure):
+    _fields_ = [("TrisNum", C.c_int32), ("BVsNum", C.c_int32), ("MaxBVHDepth", C.c_int32),
+                ("SceneBVHStartIndex", C.c_int32), ("SceneObjectsNum", C.c_int32), ("ScatterProbability", C.c_float),
+                ("Resolution", C.c_int32 * 2), ("MaxBounceCount", C.c_int32), ("RaysPerPixel", C.c_int32),
+                ("ViewSpaceDims", C.c_float * 2), ("DefocusStrength", C.c_float), ("FocalPlaneFactor", C.c_float),
+                ("WorldSpaceCameraPos", C.c_float * 3), ("CameraTransform", C.c_float * 9), ("FrameRand", C.c_int32),
+                ("FrameCount", C.c_int32), ("DebugDataMaxValues", C.c_int32 * 2),
+                ("SceneObjectCandidatesNum", C.c_int32), ("TriCandidatesNum", C.c_int32),
+                ("TotCandidatesNum", C.c_int32), ("EmittingObjectsNum", C.c_int32), ("TotArea", C.c_float),
+                ("SceneObjectReservoirTestsNum", C.c_int32), ("TriReservoirTestsNum", C.c_int32),
+                ("CandidateReservoirTestsNum", C.c_int32), ("row0", C.c_int32), ("row1", C.c_int32)]
+
+
+class OrcRisScene(C.Structure):
+    _fields_ = [("BVs", C.c_void_p), ("nBVs", C.c_int64), ("SceneObjects", C.c_void_p), ("nSceneObjects", C.c_int64),
+                ("LightObjects", C.c_void_p), ("nLightObjects", C.c_int64), ("Materials", C.c_void_p),
+                ("nMaterials", C.c_int64), ("Tris", C.c_void_p), ("nTris", C.c_int64)]
+
+
+class OrcRisFrame(C.Structure):
+    _fields_ = [("HitInfos", C.c_void_p), ("nHitInfos", C.c_int64), ("Candidates", C.c_void_p),
+                ("nCandidates", C.c_int64), ("Result", C.c_void_p), ("DebugOverlay", C.c_void_p),
+                ("RayHitPoints", C.c_void_p), ("records", C.c_void_p), ("counters", C.c_void_p)]
+
+
+def oracle_ris_lib():
+    lib = oracle_lib()
+    if not getattr(lib, "_ris_bound", False):
+        ps, pp, pf, ci = C.POINTER(OrcRisScene), C.POINTER(OrcRisParams), C.POINTER(OrcRisFrame), C.c_int
+        lib.orc_ris_calc_tri_normals.restype, lib.orc_ris_calc_tri_normals.argtypes = ci, [ps, C.c_uint32, ci]
+        for name in ("orc_ris_generate_candidates", "orc_ris_trace_rays"):
+            getattr(lib, name).restype, getattr(lib, name).argtypes = ci, [ps, pp, pf, ci]
+        u32p, fp = C.POINTER(C.c_uint32), C.POINTER(C.c_float)
+        lib.orc_ris_weighted_rand.restype, lib.orc_ris_weighted_rand.argtypes = C.c_int32, [C.c_float, C.c_float, u32p]
+        lib.orc_ris_ray_bv_intersect.restype, lib.orc_ris_ray_bv_intersect.argtypes = C.c_float, [fp, fp, C.c_void_p]
+        lib.orc_ris_ray_triangle_intersect.restype = C.c_int32
+        lib.orc_ris_ray_triangle_intersect.argtypes = [fp, fp, C.c_void_p, fp, fp]
+        lib._ris_bound = True
+    return lib
+
+
+def ris_arrays_from_scene(a, smoothness=0.0):
+    """The RIS project's triangle and material arrays derived from the ReSTIR-style scene arrays: inline vertices
+    (MeshHelper.cs:33-73), parent index = last object using the mesh (:441-450), Material2 (Main.cs:271-282)."""
+    tris = np.zeros(len(a["Triangles"]), DT["RisTri"])
+    v = a["Vertices"]
+    idx = a["Triangles"]["v"]
+    for k, name in enumerate(("A", "B", "C")):
+        tris["v" + name] = v["pos"][idx[:, k]]
+        tris["uv" + name] = v["uv"][idx[:, k]]
+    for i, o in enumerate(a["SceneObjects"]):
+        start, count = a["ComponentDatas"][o["bvStartIndex"]]
+        tris["parentIndex"][start:start + count] = i
+    mats = np.zeros(max(len(a["Materials"]), 1), DT["RisMaterial"])
+    n = len(a["Materials"])
+    mats["color"][:n] = a["Materials"]["col"]
+    mats["specularColor"][:n] = 1.0
+    mats["brightness"][:n] = a["Materials"]["brightness"]
+    mats["smoothness"][:n] = smoothness
+    return tris, mats
+
+
+class RisOracleRenderer:
+    """The RIS project's frame loop (BVH_RIS_DL Main.cs:132-144, 319-376) on the CPU oracle."""
+
+    def __init__(self, scene_arrays, cfg, threads=0, records=True, row0=0, row1=0):
+        self.lib = oracle_ris_lib()
+        self.cfg, self.threads = cfg, threads
+        a = self.a = {k: (v.copy() if isinstance(v, np.ndarray) else v) for k, v in scene_arrays.items()}
+        self.tris, self.mats = ris_arrays_from_scene(a, cfg.smoothness)
+        W, H = cfg.Resolution[0], cfg.Resolution[1]
+        self.W, self.H = W, H
+        n = W * H
+        rpp = 1  # Main.Start forces RaysPerPixel to 1 (Main.cs:92-97)
+        tot = cfg.SceneObjectCandidatesNum * cfg.TriCandidatesNum
+        self.buf = {"HitInfos": np.zeros(n, DT["RisHitInfo"]), "Candidates": np.zeros(max(n * rpp * tot, 1), DT["Float4"])}
+        self.tex = {k: np.zeros((H, W, 4), np.float32) for k in ("Result", "AccumulatedResult", "DebugOverlay", "RayHitPoints")}
+        self.records = np.zeros(n, DT["TraceRecord"]) if records else None
+        self.counters = OrcCounters()
+        self.FrameCount = 0
+        self.frames_started = 0
+        p = self.p = OrcRisParams()
+        host = rt.host_lib()
+        p.TrisNum, p.BVsNum = len(self.tris), len(a["BVs"])
+        p.MaxBVHDepth, p.SceneBVHStartIndex = a["maxBVHDepth"], a["sceneBVHStartIndex"]
+        p.SceneObjectsNum, p.EmittingObjectsNum, p.TotArea = len(a["SceneObjects"]), a["emittingObjectsNum"], a["totArea"]
+        p.ScatterProbability, p.MaxBounceCount, p.RaysPerPixel = cfg.ScatterProbability, cfg.MaxBounceCount, rpp
+        p.Resolution[0], p.Resolution[1] = W, H
+        vsd = (C.c_float * 2)()
+        host.rth_view_space_dims(cfg.fieldOfView, W, H, vsd)
+        p.ViewSpaceDims[0], p.ViewSpaceDims[1] = vsd[0], vsd[1]
+        p.DefocusStrength, p.FocalPlaneFactor = cfg.DefocusStrength, cfg.FocalPlaneFactor
+        t = (C.c_float * 16)()
+        host.rth_ris_camera_transform(cfg.cameraEulerDeg, t)
+        ct = mat3_rowmajor_from_colmajor4(list(t))
+        for i in range(3):
+            p.WorldSpaceCameraPos[i] = cfg.cameraPosition[i]
+        for i in range(9):
+            p.CameraTransform[i] = float(ct[i])
+        p.DebugDataMaxValues[0], p.DebugDataMaxValues[1] = cfg.DebugMaxTriChecks, cfg.DebugMaxBVChecks
+        p.SceneObjectCandidatesNum, p.TriCandidatesNum, p.TotCandidatesNum = cfg.SceneObjectCandidatesNum, cfg.TriCandidatesNum, tot
+        p.SceneObjectReservoirTestsNum, p.TriReservoirTestsNum = cfg.SceneObjectReservoirTestsNum, cfg.TriReservoirTestsNum
+        p.CandidateReservoirTestsNum = cfg.CandidateReservoirTestsNum
+        p.row0, p.row1 = row0, row1
+        s = self.s = OrcRisScene()
+        s.BVs, s.nBVs = a["BVs"].ctypes.data, len(a["BVs"])
+        s.SceneObjects, s.nSceneObjects = a["SceneObjects"].ctypes.data, len(a["SceneObjects"])
+        s.LightObjects, s.nLightObjects = a["LightObjects"].ctypes.data, len(a["LightObjects"])
+        s.Materials, s.nMaterials = self.mats.ctypes.data, len(self.mats)
+        s.Tris, s.nTris = self.tris.ctypes.data, len(self.tris)
+        f = self.f = OrcRisFrame()
+        f.HitInfos, f.nHitInfos = self.buf["HitInfos"].ctypes.data, n
+        f.Candidates, f.nCandidates = self.buf["Candidates"].ctypes.data, len(self.buf["Candidates"])
+        f.Result, f.DebugOverlay = self.tex["Result"].ctypes.data, self.tex["DebugOverlay"].ctypes.data
+        f.RayHitPoints = self.tex["RayHitPoints"].ctypes.data
+        f.records = self.records.ctypes.data if records else None
+        f.counters = C.addressof(self.counters)
+        assert self.lib.orc_ris_calc_tri_normals(C.byref(s), len(self.tris), threads) == 0  # RunPreCalcShader, Main.cs:298
+
+    def set_band(self, row0, row1):
+        self.p.row0, self.p.row1 = row0, row1
+
+    def update_per_frame(self):
+        cfg = self.cfg
+        self.p.FrameRand = (cfg.frameRandBase + cfg.frameRandStep * self.frames_started) % 999999
+        self.frames_started += 1
+        self.p.FrameCount = self.FrameCount
+        self.pp_frame_count = self.FrameCount
+        self.FrameCount += 1
+
+    def generate_candidates(self):
+        assert self.lib.orc_ris_generate_candidates(C.byref(self.s), C.byref(self.p), C.byref(self.f), self.threads) == 0
+
+    def trace_rays(self):
+        assert self.lib.orc_ris_trace_rays(C.byref(self.s), C.byref(self.p), C.byref(self.f), self.threads) == 0
+
+    def accumulate(self):
+        # PostProcesser.compute:10-19 is the same arithmetic as the ReSTIR project's PostProcessor
+        p = OrcParams()
+        p.Resolution[0], p.Resolution[1] = self.W, self.H
+        p.row0, p.row1 = self.p.row0, self.p.row1
+        f = OrcFrame()
+        f.Result, f.AccumulatedResult = self.tex["Result"].ctypes.data, self.tex["AccumulatedResult"].ctypes.data
+        assert self.lib.orc_accumulate_frames(C.byref(p), C.byref(f), self.pp_frame_count, self.threads) == 0
+
+    def run_stage(self, stage):
+        [self.generate_candidates, self.trace_rays][stage]()
+
+    def render_frame(self):
+        self.update_per_frame()
+        self.generate_candidates()
+        self.trace_rays()
+        self.accumulate()
+
+    def take_counters(self):
+        d = self.counters.as_dict()
+        C.memset(C.addressof(self.counters), 0, C.sizeof(self.counters))
+        return d
+
+
+def small_ris_config(w=64, h=64, tri_candidates=4, tests=3):
+    cfg = rt.ris_default_config()
+    cfg.Resolution[0], cfg.Resolution[1] = w, h
+    cfg.TriCandidatesNum = tri_candidates
+    cfg.SceneObjectReservoirTestsNum = cfg.TriReservoirTestsNum = cfg.CandidateReservoirTestsNum = tests
+    return cfg
