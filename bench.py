@@ -51,6 +51,19 @@ def algorithmic_bytes(kernel, c, npx_launch):
     return 0
 
 
+def pmc_traffic(kernel, W, H, world, small_scene):
+    """HBM bytes per launch of `kernel` from the committed PMC passes (FETCH_SIZE and WRITE_SIZE, one rocprofv3 --pmc
+    run each over this same command; tools/pmc_pass.sh, tools/pmc_to_traffic.py), or None when this run is not the
+    configuration they were collected on.  Counters cannot be read from inside the process being timed."""
+    if (W, H, world, small_scene) != (1920, 1080, 1, False):
+        return None
+    path = os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")
+    if not os.path.exists(path):
+        return None
+    k = json.load(open(path))["kernels"].get(kernel)
+    return k["hbm_bytes_per_launch"] if k else None
+
+
 def cpu_baseline(rt, scene, cfg, frames, threads):
     """The CPU oracle (a port of the reference's kernels) on the same scene, resolution and constants."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -149,7 +162,8 @@ def main():
         if dominant:
             d = timed[dominant]
             roofline = {"bound": "hbm", "kernel": dominant, "achieved": d["achieved_GBs"], "peak": HBM_PEAK_GBS,
-                        "unit": "GB/s", "frac": d["achieved_GBs"] / HBM_PEAK_GBS, "traffic": None,
+                        "unit": "GB/s", "frac": d["achieved_GBs"] / HBM_PEAK_GBS,
+                        "traffic": pmc_traffic(dominant, W, H, world, args.small_scene),
                         "avg_launch_ms": d["avg_ms"], "algorithmic_MB_per_launch": d["algorithmic_MB_per_launch"]}
         out = {
             "metric": "Mrays/s (primary+shadow) ReSTIR DL, 80kScene 1080p",
