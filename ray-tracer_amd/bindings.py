@@ -173,7 +173,8 @@ def host_lib():
             "rth_scene_create": (vp, [ci, ci]), "rth_scene_free": (None, [vp]),
             "rth_scene_add_material": (ci, [vp, C.POINTER(_MaterialInput)]), "rth_scene_add_mesh": (ci, [vp, vp]),
             "rth_scene_add_object": (ci, [vp, ci, fp, fp, fp, ci, ci]), "rth_scene_build": (ci, [vp, ci]),
-            "rth_scene_get": (ci, [vp, C.POINTER(_SceneData)]), "rth_world_to_local": (None, [fp, fp, fp, fp, fp]),
+            "rth_scene_get": (ci, [vp, C.POINTER(_SceneData)]), "rth_scene_save_json": (ci, [vp, cs]),
+            "rth_scene_load_json": (ci, [vp, cs, cs, C.c_char_p, ci]), "rth_world_to_local": (None, [fp, fp, fp, fp, fp]),
             "rth_view_space_dims": (None, [C.c_float, ci, ci, fp]), "rth_camera_matrices": (None, [fp, fp, fp, fp]),
             "rth_main_default_config": (None, [C.POINTER(MainConfig)]),
             "rth_main_create": (vp, [vp, C.POINTER(MainConfig), vp, ci, ci]), "rth_main_destroy": (None, [vp]),
@@ -289,6 +290,22 @@ class Scene:
     def build(self, threads=0):
         if host_lib().rth_scene_build(self.h, threads) != 0:
             raise NativeError("rth_scene_build failed")
+        d = _SceneData()
+        if host_lib().rth_scene_get(self.h, C.byref(d)) != 0:
+            raise NativeError("rth_scene_get failed")
+        self._data = d
+        return self
+
+    def save_json(self, folder):
+        """Writes the reference's JSON scene cache (FileLoader.cs:26-44) into an existing folder."""
+        if host_lib().rth_scene_save_json(self.h, folder.encode()) != 0:
+            raise NativeError(f"rth_scene_save_json({folder}) failed")
+
+    def load_json(self, folder, prefix=None):
+        """Fills the scene from a JSON scene cache instead of building it (materials must be registered first)."""
+        err = C.create_string_buffer(512)
+        if host_lib().rth_scene_load_json(self.h, folder.encode(), prefix.encode() if prefix else None, err, 512) != 0:
+            raise NativeError("rth_scene_load_json: " + err.value.decode())
         d = _SceneData()
         if host_lib().rth_scene_get(self.h, C.byref(d)) != 0:
             raise NativeError("rth_scene_get failed")

@@ -75,6 +75,16 @@ typedef struct {
 } rth_scene_data;
 int rth_scene_get(rth_scene s, rth_scene_data* out);
 
+/* Scene cache, JSON multi-file form (FileLoader.cs:12-91): writes `<folder>/<key>.json` for loadedBVs, loadedVertices,
+ * renderTriangles, sceneObjectDatas, lightObjects, loadedComponentDatas, integers, floats (and an empty renderBVs, as
+ * the reference's SaveToFile leaves it, ObjectHelper.cs:523-544).  The folder must exist. */
+int rth_scene_save_json(rth_scene s, const char* folder);
+/* Fills `s` from such a folder instead of building it (ConstructScene in LoadExistingFile mode,
+ * ObjectHelper.cs:672-677): the scene needs its materials registered (they are not part of the cache) but no
+ * meshes or objects.  Each file is looked up as `<key>.json` and, if `prefix` is given, `<prefix>_<key>.json`.
+ * On failure returns -1 and writes a message naming the file into `err`. */
+int rth_scene_load_json(rth_scene s, const char* folder, const char* prefix, char* err, int errLen);
+
 /* Utils.CreateWorldToLocalMatrix (Resources.cs:67-87) and its inverse, column-major. */
 void rth_world_to_local(const float position[3], const float eulerDeg[3], const float scale[3], float outW2L[16],
                         float outL2W[16]);

@@ -9,6 +9,7 @@
 //   Triangle.Initialise               BVH_ReSTIR_DL/Assets/Scripts/Data types/Other/Triangle.cs:17-46
 // CPU only; no GPU work happens here.
 #include "rth_api.h"
+#include "scene_internal.h"
 #include "unity_math.h"
 
 #include <omp.h>
@@ -197,6 +198,14 @@ inline float boxArea(V3 a, V3 b) {
     return 2 * (length * width + width * height + height * length);
 }
 
+// The same expression as the reference's runtime evaluates it for the value it STORES per scene object: the committed
+// 80kScene dump holds 422.67606 for the dragon where single-precision evaluation gives 422.6761, i.e. the products
+// and sums were carried in double precision and rounded once (Mono keeps float expressions in double registers).
+inline float boxAreaStored(V3 a, V3 b) {
+    double length = fabsf(a.x - b.x), width = fabsf(a.y - b.y), height = fabsf(a.z - b.z);
+    return (float)(2 * (length * width + width * height + height * length));
+}
+
 struct Builder {
     int splitResolution;
     std::vector<BVNode> nodes;
@@ -379,19 +388,7 @@ int rth_scene_build(rth_scene s, int threads) {
     const int nObj = (int)s->objects.size();
     const int nMesh = (int)s->meshes.size();
 
-    // ---- materials: the scalar path of ConstructTextureAtlas (:390-449) ----
-    s->materials.clear();
-    for (const auto& mi : s->materialInputs) {
-        rt_material m;
-        memset(&m, 0, sizeof m);
-        m.brightness = mi.brightness;
-        m.col = {mi.col[0], mi.col[1], mi.col[2]};
-        m.bump = mi.bump;
-        m.roughness = mi.roughness;
-        m.metallicity = mi.metallicity;
-        m.normalsTexLoc = {-1, -1};
-        s->materials.push_back(m);
-    }
+    rth_scene_make_materials(s);
 
     // ---- LoadSceneObjects (:556-607): meshes get their BVH the first time an object uses them ----
     std::vector<int> firstUseOrder;          // mesh ids in order of first use
@@ -467,7 +464,7 @@ int rth_scene_build(rth_scene s, int threads) {
     // ---- scene objects (:561-602) + ConstructSceneBVH (:609-664) ----
     std::vector<rt_scene_object> objs(nObj);
     int maxBVHDepth = s->maxDepthSceneBVH;
-    float totArea = 0;
+    double totArea = 0;  // rounded once at the end, see boxAreaStored
     for (int i = 0; i < nObj; i++) {
         const ObjectDesc& o = s->objects[i];
         rt_scene_object d;
@@ -488,7 +485,7 @@ int rth_scene_build(rth_scene s, int threads) {
         for (auto& c : corners) { V3 w = mulPoint(l2w, c); wmin = vmin(wmin, w); wmax = vmax(wmax, w); }
         d.min = toR3(wmin);
         d.max = toR3(wmax);
-        d.areaApprox = boxArea(wmin, wmax);
+        d.areaApprox = boxAreaStored(wmin, wmax);
         totArea += d.areaApprox;  // the reference adds these from a Parallel.For (:618-636); order fixed here
         objs[i] = d;
     }
@@ -529,10 +526,36 @@ int rth_scene_build(rth_scene s, int threads) {
     s->maxBVHDepth = maxBVHDepth;
     s->emittingObjectsNum = emitting;
     s->sceneBVHStartIndex = sceneBVHStartIndex;
-    s->totArea = totArea;
+    s->totArea = (float)totArea;
     s->built = true;
     return 0;
 }
+
+}  // extern "C"
+
+// Internal door for scene_cache.cpp: the arrays ConstructScene returns, for writing them out or filling them in.
+SceneArraysRef rth_scene_arrays_ref(rth_scene s) {
+    SceneArraysRef r = {&s->BVs, &s->componentDatas, &s->vertices, &s->triangles, &s->sceneObjects, &s->lightObjects,
+                        &s->maxBVHDepth, &s->emittingObjectsNum, &s->sceneBVHStartIndex, &s->totArea, &s->built};
+    return r;
+}
+// The scalar path of ConstructTextureAtlas (ObjectHelper.cs:390-449): one Material2 per registered material input.
+void rth_scene_make_materials(rth_scene s) {
+    s->materials.clear();
+    for (const auto& mi : s->materialInputs) {
+        rt_material m;
+        memset(&m, 0, sizeof m);
+        m.brightness = mi.brightness;
+        m.col = {mi.col[0], mi.col[1], mi.col[2]};
+        m.bump = mi.bump;
+        m.roughness = mi.roughness;
+        m.metallicity = mi.metallicity;
+        m.normalsTexLoc = {-1, -1};
+        s->materials.push_back(m);
+    }
+}
+
+extern "C" {
 
 int rth_scene_get(rth_scene s, rth_scene_data* out) {
     if (!s || !out || !s->built) return -1;
