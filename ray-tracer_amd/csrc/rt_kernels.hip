@@ -31,12 +31,14 @@ constexpr int WAVES_PER_BLOCK = 4;
 #define RT_MIN_WAVES 1
 #endif
 #ifndef RT_TRAVERSE_V
-#define RT_TRAVERSE_V 2
+#define RT_TRAVERSE_V 3
 #endif
 #if RT_TRAVERSE_V == 1
 #define TRAVERSE traverse
-#else
+#elif RT_TRAVERSE_V == 2
 #define TRAVERSE traverse2
+#else
+#define TRAVERSE traverse3
 #endif
 
 struct v2 { float x, y; };
@@ -495,6 +497,147 @@ DEV void traverse2(const KParams& P, const v3 wpos, const v3 wdir, const v3 winv
                 }
             }
             alive = nextEntry<INSTR>(P, wpos, wdir, winv, stk, s, t, e);
+        }
+    }
+    t.dst = s.worldBest;
+}
+
+// ---- third formulation: rare work moved out of the hot loop -----------------------------------------------------
+// Same visit order as traverse2, but leaving an object (RS:251-258), entering the next one (RS:235-246: two matrix
+// products and three IEEE divisions) and finishing the ray are no longer part of every trip of the internal-node
+// loop: a lane that needs one of them holds ENTRY_NONE and waits, and all such lanes are served together in a
+// "service" step once per outer trip.  With 64 lanes at different places in their trees, almost every trip of the
+// traverse2 loop had SOME lane on that path, so every trip paid for its ~200 instructions; a ray needs it only a
+// handful of times.  Taking the next entry from the stack stays inline (one LDS read).
+template <bool INSTR, bool RIS = false>
+DEV void traverse3(const KParams& P, const v3 wpos, const v3 wdir, const v3 winv, uint32_t* stk, Trav& t) {
+    TravState s;
+    s.rpos = wpos; s.rdir = wdir; s.rinv = winv;
+    s.best = INF(); s.worldBest = INF();
+    s.sp = 0; s.objBase = -1; s.objCur = 0; s.objEnd = 0; s.curObj = -1; s.localTri = -1;
+    s.localU = 0; s.localV = 0;
+    t.tri = -1; t.obj = -1; t.u = 0; t.v = 0; t.triChecks = 0; t.bvChecks = 0;
+    if (INSTR) { t.hash = 2166136261u; t.pops = 1; t.objVisits = 0; t.triIters = 0; t.iters = 0; }
+    const int cap = P.stackDepth;
+    uint32_t e = P.sceneRootEntry;
+    bool alive = true;
+    constexpr uint32_t LEAF_BITS = ENTRY_LEAF | ENTRY_LEAF_INDIRECT;
+    // next entry of the level being traversed, or ENTRY_NONE when that level's part of the stack is used up
+    auto popInline = [&]() {
+        const int floor = s.objBase >= 0 ? s.objBase : 0;
+        if (s.sp > floor) {
+            --s.sp;
+            e = s.sp < cap ? stk[s.sp * 64] : ENTRY_LEAF;
+            if (INSTR) t.pops++;
+        } else {
+            e = ENTRY_NONE;
+        }
+    };
+    while (__builtin_amdgcn_ballot_w64(alive) != 0) {
+        // ---------- service: object exit / object entry / scene-level pop / end of ray ----------
+        if (alive && e == ENTRY_NONE) {
+            if (s.objBase >= 0) {  // the object's subtree is exhausted (RS:251-258)
+                if (s.best < s.worldBest) { s.worldBest = s.best; t.tri = s.localTri; t.obj = s.curObj; t.u = s.localU; t.v = s.localV; }
+                s.best = s.worldBest;
+                s.rpos = wpos; s.rdir = wdir; s.rinv = winv;
+                s.objBase = -1;
+            }
+            if (s.objCur < s.objEnd) {  // next scene object of the current scene-level leaf (RS:235-246)
+                const float* m = P.objs[s.objCur].worldToLocalMatrix.m;
+                s.rpos = mul44(m, wpos, 1.0f);
+                s.rdir = mul44(m, wdir, 0.0f);
+                if (!RIS) s.rinv = rcp3(s.rdir);
+                s.best = INF();
+                s.localTri = -1;
+                s.curObj = s.objCur;
+                s.objBase = s.sp;
+                e = P.objRootEntry[s.objCur];
+                s.objCur++;
+                if (INSTR) { t.objVisits++; t.pops++; }
+            } else if (s.sp == 0) {
+                alive = false;
+            } else {
+                --s.sp;
+                e = s.sp < cap ? stk[s.sp * 64] : ENTRY_LEAF;
+                if (INSTR) t.pops++;
+            }
+        }
+        // ---------- internal-node phase ----------
+        for (;;) {
+            const bool isInt = alive && e != ENTRY_NONE && (e & LEAF_BITS) == 0;
+            if (__builtin_amdgcn_ballot_w64(isInt) == 0) break;
+            if (isInt) {
+                if (INSTR) { t.iters++; t.hash = (t.hash ^ (0x80000000u | e)) * 16777619u; }
+                const float4* rec = P.wide + (int64_t)e * 4;
+                const float4 q0 = rec[0], q1 = rec[1], q2 = rec[2], q3 = rec[3];
+                const float dstA = RIS ? RayBVIntersectDiv(s.rpos, s.rdir, V3(q0.x, q0.y, q0.z), V3(q0.w, q1.x, q1.y))
+                                       : RayBVIntersect(s.rpos, s.rinv, V3(q0.x, q0.y, q0.z), V3(q0.w, q1.x, q1.y));
+                const float dstB = RIS ? RayBVIntersectDiv(s.rpos, s.rdir, V3(q1.z, q1.w, q2.x), V3(q2.y, q2.z, q2.w))
+                                       : RayBVIntersect(s.rpos, s.rinv, V3(q1.z, q1.w, q2.x), V3(q2.y, q2.z, q2.w));
+                t.bvChecks += 2;
+                const uint32_t eA = __float_as_uint(q3.x), eB = __float_as_uint(q3.y);
+                const bool aFirst = dstA < dstB;  // RS:204-214: the nearer child is visited first
+                const uint32_t eNear = aFirst ? eA : eB, eFar = aFirst ? eB : eA;
+                const bool nearHit = (aFirst ? dstA : dstB) < s.best, farHit = (aFirst ? dstB : dstA) < s.best;
+                if (nearHit) {
+                    if (farHit) { if (s.sp < cap) stk[s.sp * 64] = eFar; s.sp++; }
+                    e = eNear;
+                    if (INSTR) t.pops++;
+                } else if (farHit) {
+                    e = eFar;
+                    if (INSTR) t.pops++;
+                } else {
+                    popInline();
+                }
+            }
+            // leave the phase once at least half of the lanes still at work wait for a leaf or for service
+            const unsigned long long waitMask = __builtin_amdgcn_ballot_w64(alive && (e == ENTRY_NONE || (e & LEAF_BITS) != 0));
+            if (RT_LEAF_DEN * __builtin_popcountll(waitMask) >= RT_LEAF_NUM * __builtin_popcountll(__builtin_amdgcn_ballot_w64(alive))) break;
+        }
+        // ---------- leaf phase ----------
+        if (alive && e != ENTRY_NONE && (e & LEAF_BITS) != 0) {
+            int start, count;
+            if (e & ENTRY_LEAF) {
+                start = (int)(e & (uint32_t)ENTRY_INLINE_MAX_START);
+                count = (int)((e >> 26) & 31u);
+                if (INSTR) { t.hash = (t.hash ^ (uint32_t)start) * 16777619u; t.hash = (t.hash ^ (uint32_t)count) * 16777619u; }
+            } else {
+                const rt_bv* bv = &P.BVs[e & ENTRY_INDEX_MASK];
+                int a = bv->indexA, b = bv->indexB;
+                if (INSTR) { t.hash = (t.hash ^ (uint32_t)a) * 16777619u; t.hash = (t.hash ^ (uint32_t)b) * 16777619u; }
+                start = a < 0 ? -a : a;
+                count = b < 0 ? -b : b;
+            }
+            if (INSTR) t.iters++;
+            if (s.objBase < 0) {  // scene-level leaf: a run of scene objects, entered one by one by the service step
+                s.objCur = start;
+                s.objEnd = start + count;
+                e = ENTRY_NONE;
+            } else {
+                for (int triIndex = start; triIndex < start + count; triIndex++) {  // RS:179-193
+                    const float4* rec = P.btri + (int64_t)triIndex * 4;
+                    if (INSTR) t.triIters++;
+                    bool facing = true;
+                    if (!RIS) { const float4 q3 = rec[3]; facing = dot(V3(q3.x, q3.y, q3.z), s.rdir) <= 0; }
+                    if (facing) {
+                        const float4 q0 = rec[0], q1 = rec[1], q2 = rec[2];
+                        v3 edgeAB = V3(q1.x, q1.y, q1.z), edgeAC = V3(q2.x, q2.y, q2.z);
+                        v3 normalVector = V3(q0.w, q1.w, q2.w);
+                        v3 ao = s.rpos - V3(q0.x, q0.y, q0.z);
+                        v3 dao = cross(ao, s.rdir);
+                        float determinant = -dot(s.rdir, normalVector);
+                        float invDet = 1 / determinant;
+                        float dst = dot(ao, normalVector) * invDet;
+                        float u = dot(edgeAC, dao) * invDet;
+                        float v = -dot(edgeAB, dao) * invDet;
+                        float w = 1 - u - v;
+                        bool didHit = determinant >= 1E-8f && dst >= 0 && u >= 0 && v >= 0 && w >= 0;
+                        t.triChecks++;
+                        if (didHit && dst < s.best) { s.best = dst; s.localU = u; s.localV = v; s.localTri = triIndex; }
+                    }
+                }
+                popInline();
+            }
         }
     }
     t.dst = s.worldBest;
