@@ -30,16 +30,7 @@ constexpr int WAVES_PER_BLOCK = 4;
 #ifndef RT_MIN_WAVES
 #define RT_MIN_WAVES 1
 #endif
-#ifndef RT_TRAVERSE_V
-#define RT_TRAVERSE_V 3
-#endif
-#if RT_TRAVERSE_V == 1
-#define TRAVERSE traverse
-#elif RT_TRAVERSE_V == 2
-#define TRAVERSE traverse2
-#else
 #define TRAVERSE traverse3
-#endif
 
 struct v2 { float x, y; };
 struct v3 { float x, y, z; };
@@ -247,400 +238,183 @@ DEV float RayBVIntersectDiv(v3 pos, v3 dir, v3 bmin, v3 bmax) {
     return didHit ? (tNear > 0 ? tNear : 0.0f) : INF();
 }
 
-// GetRayCollision (RS:284-291) = TraverseSceneBVH (RS:219-282) + TraverseTrisBVH (RS:163-217), as one loop over
-// one stack.  `stk` points at this lane's column of the LDS stack (entries 64 dwords apart).  Visit order, the
-// near-first push rule and the strict `<` culls are the reference's; only what is fetched per step differs.
-// Shading data of the winning triangle (uv, normals, hit point) is derived afterwards from (tri, obj, u, v).
-template <bool INSTR>
-DEV void traverse(const KParams& P, const v3 wpos, const v3 wdir, const v3 winv, uint32_t* stk, Trav& t) {
-    v3 rpos = wpos, rdir = wdir, rinv = winv;
-    float best = INF();       // hitInfo.dst of the level being traversed (world level / object level)
-    float worldBest = INF();
-    int sp = 0, objBase = -1, objCur = 0, objEnd = 0, curObj = -1, localTri = -1;
-    float localU = 0, localV = 0;
-    t.tri = -1; t.obj = -1; t.u = 0; t.v = 0; t.triChecks = 0; t.bvChecks = 0;
-    if (INSTR) { t.hash = 2166136261u; t.pops = 0; t.objVisits = 0; t.triIters = 0; t.iters = 0; }
-    const int cap = P.stackDepth;
-    stk[0] = P.sceneRootEntry;
-    sp = 1;
-    for (;;) {
-        if (INSTR) t.iters++;
-        if (objBase < 0) {
-            if (objCur < objEnd) {
-                // next scene object of the current scene-level leaf (RS:235-246)
-                const rt_scene_object* o = &P.objs[objCur];
-                const float* m = o->worldToLocalMatrix.m;
-                rpos = mul44(m, wpos, 1.0f);
-                rdir = mul44(m, wdir, 0.0f);
-                rinv = rcp3(rdir);
-                best = INF();
-                localTri = -1;
-                curObj = objCur;
-                objBase = sp;
-                if (sp < cap) stk[sp * 64] = P.objRootEntry[objCur];
-                sp++;
-                objCur++;
-                if (INSTR) t.objVisits++;
-                continue;
-            }
-            if (sp == 0) break;
-        } else if (sp == objBase) {
-            // the object's tree is exhausted (RS:251-258)
-            if (best < worldBest) { worldBest = best; t.tri = localTri; t.obj = curObj; t.u = localU; t.v = localV; }
-            best = worldBest;
-            rpos = wpos; rdir = wdir; rinv = winv;
-            objBase = -1;
-            continue;
-        }
-        --sp;
-        const uint32_t e = sp < cap ? stk[sp * 64] : (ENTRY_LEAF);  // overflowed pushes pop as empty leaves
-        if (INSTR) t.pops++;
-        if (e & (ENTRY_LEAF | ENTRY_LEAF_INDIRECT)) {
-            int start, count;
-            if (e & ENTRY_LEAF) {
-                start = (int)(e & (uint32_t)ENTRY_INLINE_MAX_START);
-                count = (int)((e >> 26) & 31u);
-                if (INSTR) { t.hash = (t.hash ^ (uint32_t)start) * 16777619u; t.hash = (t.hash ^ (uint32_t)count) * 16777619u; }
-            } else {
-                const rt_bv* bv = &P.BVs[e & ENTRY_INDEX_MASK];
-                int a = bv->indexA, b = bv->indexB;
-                if (INSTR) { t.hash = (t.hash ^ (uint32_t)a) * 16777619u; t.hash = (t.hash ^ (uint32_t)b) * 16777619u; }
-                start = a < 0 ? -a : a;
-                count = b < 0 ? -b : b;
-            }
-            if (objBase < 0) {  // scene-level leaf: a run of scene objects
-                objCur = start;
-                objEnd = start + count;
-                continue;
-            }
-            for (int triIndex = start; triIndex < start + count; triIndex++) {  // RS:179-193
-                const float4* rec = P.btri + (int64_t)triIndex * 4;
-                const float4 q3 = rec[3];
-                if (INSTR) t.triIters++;
-                if (dot(V3(q3.x, q3.y, q3.z), rdir) <= 0) {
-                    const float4 q0 = rec[0], q1 = rec[1], q2 = rec[2];
-                    // RayTriangleIntersect, RS:119-146
-                    v3 edgeAB = V3(q1.x, q1.y, q1.z), edgeAC = V3(q2.x, q2.y, q2.z);
-                    v3 normalVector = V3(q0.w, q1.w, q2.w);
-                    v3 ao = rpos - V3(q0.x, q0.y, q0.z);
-                    v3 dao = cross(ao, rdir);
-                    float determinant = -dot(rdir, normalVector);
-                    float invDet = 1 / determinant;
-                    float dst = dot(ao, normalVector) * invDet;
-                    float u = dot(edgeAC, dao) * invDet;
-                    float v = -dot(edgeAB, dao) * invDet;
-                    float w = 1 - u - v;
-                    bool didHit = determinant >= 1E-8f && dst >= 0 && u >= 0 && v >= 0 && w >= 0;
-                    t.triChecks++;
-                    if (didHit && dst < best) { best = dst; localU = u; localV = v; localTri = triIndex; }
-                }
-            }
-        } else {
-            const float4* rec = P.wide + (int64_t)e * 4;
-            const float4 q0 = rec[0], q1 = rec[1], q2 = rec[2], q3 = rec[3];
-            if (INSTR) t.hash = (t.hash ^ (0x80000000u | e)) * 16777619u;
-            float dstA = RayBVIntersect(rpos, rinv, V3(q0.x, q0.y, q0.z), V3(q0.w, q1.x, q1.y));
-            float dstB = RayBVIntersect(rpos, rinv, V3(q1.z, q1.w, q2.x), V3(q2.y, q2.z, q2.w));
-            t.bvChecks += 2;
-            const uint32_t eA = __float_as_uint(q3.x), eB = __float_as_uint(q3.y);
-            // push the nearer child last so it is visited first (RS:204-214)
-            const bool aFirst = dstA < dstB;
-            const uint32_t e1 = aFirst ? eB : eA, e2 = aFirst ? eA : eB;
-            const float d1 = aFirst ? dstB : dstA, d2 = aFirst ? dstA : dstB;
-            if (d1 < best) { if (sp < cap) stk[sp * 64] = e1; sp++; }
-            if (d2 < best) { if (sp < cap) stk[sp * 64] = e2; sp++; }
-        }
-    }
-    t.dst = worldBest;
-}
-
-// ---- second formulation of the same traversal, organised for 64-lane execution -------------------------------
-// The entry to visit next stays in a register (`e`); only the FAR child of an internal node goes to the LDS stack
-// (the reference pushes far then near and pops near at once: same order, half the stack traffic).  Each trip of
-// the outer loop runs an internal-node phase — every lane that holds an internal entry steps down the tree until
-// it holds a leaf, or is done, or enough lanes are waiting with a leaf — and then a leaf phase in which the waiting
-// lanes test their triangles together.  Keeping the two kinds of work in separate phases is what keeps the 64
-// lanes on the same instructions: in a single mixed loop nearly every trip pays for both.
-constexpr uint32_t ENTRY_NONE = 0xffffffffu;  // no entry held: take one from the stack (never a valid entry: an
-                                              // inline leaf with count 31 at start 2^26-1 is rejected at build)
+// GetRayCollision (RS:284-291) = TraverseSceneBVH (RS:219-282) + TraverseTrisBVH (RS:163-217), as one loop over one
+// stack.  `stk` points at this lane's column of the LDS stack (entries 64 dwords apart).  Visit order, the near-first
+// rule and the strict `<` culls are the reference's; only what is fetched per step, and when, differs.  Shading data
+// of the winning triangle (uv, normals, hit point) is derived afterwards from (tri, obj, u, v).
+//
+// Organisation for 64-lane execution:
+//   * the entry to visit next stays in a register (`e`); only the FAR child of an internal node goes to the LDS stack
+//     (the reference pushes far then near and pops near at once: same order, half the stack traffic);
+//   * each outer trip runs an internal-node phase - every lane that holds an internal entry steps down the tree until
+//     at least half of the lanes still at work are waiting - and then a leaf phase in which the waiting lanes test
+//     their triangles together; in a single mixed loop nearly every trip pays for both kinds of work;
+//   * leaving an object (RS:251-258), entering the next one (RS:235-246: two matrix products, three IEEE divisions)
+//     and ending the ray are a third, "service" step: a lane that needs it holds ENTRY_NONE and waits.  A ray needs
+//     it a handful of times, but with 64 lanes at different places almost every trip had some lane on that path.
+// RIS = the RIS project's traversal (BVH_RIS_DL .../RIS_BVH_RayTracer.compute:126-238): same loops, but the box test
+// divides by the direction and the leaf loop has no back-face pre-cull.
+constexpr uint32_t ENTRY_NONE = 0xffffffffu;  // no entry held (never a valid entry: an inline leaf with count 31 at
+                                              // start 2^26-1 is rejected when the scene is validated)
+constexpr uint32_t LEAF_BITS = ENTRY_LEAF | ENTRY_LEAF_INDIRECT;
 struct TravState {
+    v3 wpos, wdir, winv;     // the ray in world space
     v3 rpos, rdir, rinv;     // ray of the level being traversed (world at scene level, object space inside an object)
     float best, worldBest;   // hitInfo.dst of the level being traversed / of the world level
     int sp, objBase, objCur, objEnd, curObj, localTri;
     float localU, localV;
+    uint32_t e;              // entry to visit next, or ENTRY_NONE
 };
 
-// Takes the next entry to visit: leaves an object whose subtree is exhausted (RS:251-258), enters the next scene
-// object of the current scene-level leaf (RS:235-246), or pops the stack.  Returns false when the ray is finished.
 template <bool INSTR>
-DEV bool nextEntry(const KParams& P, const v3 wpos, const v3 wdir, const v3 winv, uint32_t* stk, TravState& s, Trav& t,
-                   uint32_t& e) {
-    for (;;) {
-        if (s.objBase >= 0) {
-            if (s.sp != s.objBase) break;
-            if (s.best < s.worldBest) { s.worldBest = s.best; t.tri = s.localTri; t.obj = s.curObj; t.u = s.localU; t.v = s.localV; }
-            s.best = s.worldBest;
-            s.rpos = wpos; s.rdir = wdir; s.rinv = winv;
-            s.objBase = -1;
-        }
-        if (s.objCur < s.objEnd) {
-            const float* m = P.objs[s.objCur].worldToLocalMatrix.m;
-            s.rpos = mul44(m, wpos, 1.0f);
-            s.rdir = mul44(m, wdir, 0.0f);
-            s.rinv = rcp3(s.rdir);
-            s.best = INF();
-            s.localTri = -1;
-            s.curObj = s.objCur;
-            s.objBase = s.sp;
-            e = P.objRootEntry[s.objCur];
-            s.objCur++;
-            if (INSTR) { t.objVisits++; t.pops++; }
-            return true;
-        }
-        if (s.sp == 0) { e = ENTRY_NONE; return false; }
-        break;
+DEV void travBegin(const KParams& P, TravState& s, Trav& t, v3 wpos, v3 wdir, v3 winv) {
+    s.wpos = wpos; s.wdir = wdir; s.winv = winv;
+    s.rpos = wpos; s.rdir = wdir; s.rinv = winv;
+    s.best = INF(); s.worldBest = INF();
+    s.sp = 0; s.objBase = -1; s.objCur = 0; s.objEnd = 0; s.curObj = -1; s.localTri = -1;
+    s.localU = 0; s.localV = 0;
+    s.e = P.sceneRootEntry;
+    t.tri = -1; t.obj = -1; t.u = 0; t.v = 0; t.triChecks = 0; t.bvChecks = 0;
+    if (INSTR) { t.hash = 2166136261u; t.pops = 1; t.objVisits = 0; t.triIters = 0; t.iters = 0; }
+}
+// Next entry of the level being traversed, or ENTRY_NONE when that level's part of the stack is used up.
+template <bool INSTR>
+DEV void travPop(const KParams& P, TravState& s, Trav& t, const uint32_t* stk) {
+    const int floor = s.objBase >= 0 ? s.objBase : 0;
+    if (s.sp > floor) {
+        --s.sp;
+        s.e = s.sp < P.stackDepth ? stk[s.sp * 64] : ENTRY_LEAF;  // overflowed pushes come back as empty leaves
+        if (INSTR) t.pops++;
+    } else {
+        s.e = ENTRY_NONE;
     }
+}
+// Service step of one lane that holds ENTRY_NONE.  Returns false when the ray is finished.
+template <bool INSTR, bool RIS>
+DEV bool travService(const KParams& P, TravState& s, Trav& t, const uint32_t* stk) {
+    if (s.objBase >= 0) {  // the object's subtree is exhausted (RS:251-258)
+        if (s.best < s.worldBest) { s.worldBest = s.best; t.tri = s.localTri; t.obj = s.curObj; t.u = s.localU; t.v = s.localV; }
+        s.best = s.worldBest;
+        s.rpos = s.wpos; s.rdir = s.wdir; s.rinv = s.winv;
+        s.objBase = -1;
+    }
+    if (s.objCur < s.objEnd) {  // next scene object of the current scene-level leaf (RS:235-246)
+        const float* m = P.objs[s.objCur].worldToLocalMatrix.m;
+        s.rpos = mul44(m, s.wpos, 1.0f);
+        s.rdir = mul44(m, s.wdir, 0.0f);
+        if (!RIS) s.rinv = rcp3(s.rdir);
+        s.best = INF();
+        s.localTri = -1;
+        s.curObj = s.objCur;
+        s.objBase = s.sp;
+        s.e = P.objRootEntry[s.objCur];
+        s.objCur++;
+        if (INSTR) { t.objVisits++; t.pops++; }
+        return true;
+    }
+    if (s.sp == 0) { t.dst = s.worldBest; return false; }
     --s.sp;
-    e = s.sp < P.stackDepth ? stk[s.sp * 64] : ENTRY_LEAF;
+    s.e = s.sp < P.stackDepth ? stk[s.sp * 64] : ENTRY_LEAF;
     if (INSTR) t.pops++;
     return true;
 }
-
-// RIS = the RIS project's traversal (RIS_BVH_RayTracer.compute:126-238): same loops, but the box test divides by
-// the direction and the leaf loop has no back-face pre-cull.
-template <bool INSTR, bool RIS = false>
-DEV void traverse2(const KParams& P, const v3 wpos, const v3 wdir, const v3 winv, uint32_t* stk, Trav& t) {
-    TravState s;
-    s.rpos = wpos; s.rdir = wdir; s.rinv = winv;
-    s.best = INF(); s.worldBest = INF();
-    s.sp = 0; s.objBase = -1; s.objCur = 0; s.objEnd = 0; s.curObj = -1; s.localTri = -1;
-    s.localU = 0; s.localV = 0;
-    t.tri = -1; t.obj = -1; t.u = 0; t.v = 0; t.triChecks = 0; t.bvChecks = 0;
-    if (INSTR) { t.hash = 2166136261u; t.pops = 1; t.objVisits = 0; t.triIters = 0; t.iters = 0; }
-    const int cap = P.stackDepth;
-    uint32_t e = P.sceneRootEntry;
-    bool alive = true;
-    while (__builtin_amdgcn_ballot_w64(alive) != 0) {
-        // ---------- internal-node phase ----------
-        for (;;) {
-            const bool isInt = alive && (e & (ENTRY_LEAF | ENTRY_LEAF_INDIRECT)) == 0;
-            const unsigned long long intMask = __builtin_amdgcn_ballot_w64(isInt);
-            if (intMask == 0) break;
-            if (isInt) {
-                if (INSTR) { t.iters++; t.hash = (t.hash ^ (0x80000000u | e)) * 16777619u; }
-                const float4* rec = P.wide + (int64_t)e * 4;
-                const float4 q0 = rec[0], q1 = rec[1], q2 = rec[2], q3 = rec[3];
-                const float dstA = RIS ? RayBVIntersectDiv(s.rpos, s.rdir, V3(q0.x, q0.y, q0.z), V3(q0.w, q1.x, q1.y))
-                                       : RayBVIntersect(s.rpos, s.rinv, V3(q0.x, q0.y, q0.z), V3(q0.w, q1.x, q1.y));
-                const float dstB = RIS ? RayBVIntersectDiv(s.rpos, s.rdir, V3(q1.z, q1.w, q2.x), V3(q2.y, q2.z, q2.w))
-                                       : RayBVIntersect(s.rpos, s.rinv, V3(q1.z, q1.w, q2.x), V3(q2.y, q2.z, q2.w));
-                t.bvChecks += 2;
-                const uint32_t eA = __float_as_uint(q3.x), eB = __float_as_uint(q3.y);
-                const bool aFirst = dstA < dstB;  // RS:204-214: the nearer child is visited first
-                const uint32_t eNear = aFirst ? eA : eB, eFar = aFirst ? eB : eA;
-                const bool nearHit = (aFirst ? dstA : dstB) < s.best, farHit = (aFirst ? dstB : dstA) < s.best;
-                if (nearHit) {
-                    if (farHit) { if (s.sp < cap) stk[s.sp * 64] = eFar; s.sp++; }
-                    e = eNear;
-                    if (INSTR) t.pops++;
-                } else if (farHit) {
-                    e = eFar;
-                    if (INSTR) t.pops++;
-                } else {
-                    alive = nextEntry<INSTR>(P, wpos, wdir, winv, stk, s, t, e);
-                }
-            }
-            // leave the phase early once at least half of the lanes still at work are waiting with a leaf
-            const unsigned long long leafMask = __builtin_amdgcn_ballot_w64(alive && (e & (ENTRY_LEAF | ENTRY_LEAF_INDIRECT)) != 0);
-            if (RT_LEAF_DEN * __builtin_popcountll(leafMask) >= RT_LEAF_NUM * __builtin_popcountll(__builtin_amdgcn_ballot_w64(alive))) break;
-        }
-        // ---------- leaf phase ----------
-        if (alive && (e & (ENTRY_LEAF | ENTRY_LEAF_INDIRECT)) != 0) {
-            int start, count;
-            if (e & ENTRY_LEAF) {
-                start = (int)(e & (uint32_t)ENTRY_INLINE_MAX_START);
-                count = (int)((e >> 26) & 31u);
-                if (INSTR) { t.hash = (t.hash ^ (uint32_t)start) * 16777619u; t.hash = (t.hash ^ (uint32_t)count) * 16777619u; }
-            } else {
-                const rt_bv* bv = &P.BVs[e & ENTRY_INDEX_MASK];
-                int a = bv->indexA, b = bv->indexB;
-                if (INSTR) { t.hash = (t.hash ^ (uint32_t)a) * 16777619u; t.hash = (t.hash ^ (uint32_t)b) * 16777619u; }
-                start = a < 0 ? -a : a;
-                count = b < 0 ? -b : b;
-            }
-            if (INSTR) t.iters++;
-            if (s.objBase < 0) {  // scene-level leaf: a run of scene objects
-                s.objCur = start;
-                s.objEnd = start + count;
-            } else {
-                for (int triIndex = start; triIndex < start + count; triIndex++) {  // RS:179-193
-                    const float4* rec = P.btri + (int64_t)triIndex * 4;
-                    if (INSTR) t.triIters++;
-                    bool facing = true;
-                    if (!RIS) { const float4 q3 = rec[3]; facing = dot(V3(q3.x, q3.y, q3.z), s.rdir) <= 0; }
-                    if (facing) {
-                        const float4 q0 = rec[0], q1 = rec[1], q2 = rec[2];
-                        v3 edgeAB = V3(q1.x, q1.y, q1.z), edgeAC = V3(q2.x, q2.y, q2.z);
-                        v3 normalVector = V3(q0.w, q1.w, q2.w);
-                        v3 ao = s.rpos - V3(q0.x, q0.y, q0.z);
-                        v3 dao = cross(ao, s.rdir);
-                        float determinant = -dot(s.rdir, normalVector);
-                        float invDet = 1 / determinant;
-                        float dst = dot(ao, normalVector) * invDet;
-                        float u = dot(edgeAC, dao) * invDet;
-                        float v = -dot(edgeAB, dao) * invDet;
-                        float w = 1 - u - v;
-                        bool didHit = determinant >= 1E-8f && dst >= 0 && u >= 0 && v >= 0 && w >= 0;
-                        t.triChecks++;
-                        if (didHit && dst < s.best) { s.best = dst; s.localU = u; s.localV = v; s.localTri = triIndex; }
-                    }
-                }
-            }
-            alive = nextEntry<INSTR>(P, wpos, wdir, winv, stk, s, t, e);
+// One internal-node step of one lane (RS:195-214).
+template <bool INSTR, bool RIS>
+DEV void travInternal(const KParams& P, TravState& s, Trav& t, uint32_t* stk) {
+    const uint32_t e = s.e;
+    if (INSTR) { t.iters++; t.hash = (t.hash ^ (0x80000000u | e)) * 16777619u; }
+    const float4* rec = P.wide + (int64_t)e * 4;
+    const float4 q0 = rec[0], q1 = rec[1], q2 = rec[2], q3 = rec[3];
+    const float dstA = RIS ? RayBVIntersectDiv(s.rpos, s.rdir, V3(q0.x, q0.y, q0.z), V3(q0.w, q1.x, q1.y))
+                           : RayBVIntersect(s.rpos, s.rinv, V3(q0.x, q0.y, q0.z), V3(q0.w, q1.x, q1.y));
+    const float dstB = RIS ? RayBVIntersectDiv(s.rpos, s.rdir, V3(q1.z, q1.w, q2.x), V3(q2.y, q2.z, q2.w))
+                           : RayBVIntersect(s.rpos, s.rinv, V3(q1.z, q1.w, q2.x), V3(q2.y, q2.z, q2.w));
+    t.bvChecks += 2;
+    const uint32_t eA = __float_as_uint(q3.x), eB = __float_as_uint(q3.y);
+    const bool aFirst = dstA < dstB;  // the nearer child is visited first
+    const uint32_t eNear = aFirst ? eA : eB, eFar = aFirst ? eB : eA;
+    const bool nearHit = (aFirst ? dstA : dstB) < s.best, farHit = (aFirst ? dstB : dstA) < s.best;
+    if (nearHit) {
+        if (farHit) { if (s.sp < P.stackDepth) stk[s.sp * 64] = eFar; s.sp++; }
+        s.e = eNear;
+        if (INSTR) t.pops++;
+    } else if (farHit) {
+        s.e = eFar;
+        if (INSTR) t.pops++;
+    } else {
+        travPop<INSTR>(P, s, t, stk);
+    }
+}
+// Leaf step of one lane: a run of scene objects at scene level, a run of triangles inside an object (RS:179-193).
+template <bool INSTR, bool RIS>
+DEV void travLeaf(const KParams& P, TravState& s, Trav& t, const uint32_t* stk) {
+    const uint32_t e = s.e;
+    int start, count;
+    if (e & ENTRY_LEAF) {
+        start = (int)(e & (uint32_t)ENTRY_INLINE_MAX_START);
+        count = (int)((e >> 26) & 31u);
+        if (INSTR) { t.hash = (t.hash ^ (uint32_t)start) * 16777619u; t.hash = (t.hash ^ (uint32_t)count) * 16777619u; }
+    } else {
+        const rt_bv* bv = &P.BVs[e & ENTRY_INDEX_MASK];
+        int a = bv->indexA, b = bv->indexB;
+        if (INSTR) { t.hash = (t.hash ^ (uint32_t)a) * 16777619u; t.hash = (t.hash ^ (uint32_t)b) * 16777619u; }
+        start = a < 0 ? -a : a;
+        count = b < 0 ? -b : b;
+    }
+    if (INSTR) t.iters++;
+    if (s.objBase < 0) {  // scene-level leaf: its objects are entered one by one by the service step
+        s.objCur = start;
+        s.objEnd = start + count;
+        s.e = ENTRY_NONE;
+        return;
+    }
+    for (int triIndex = start; triIndex < start + count; triIndex++) {
+        const float4* rec = P.btri + (int64_t)triIndex * 4;
+        if (INSTR) t.triIters++;
+        bool facing = true;
+        if (!RIS) { const float4 q3 = rec[3]; facing = dot(V3(q3.x, q3.y, q3.z), s.rdir) <= 0; }
+        if (facing) {
+            const float4 q0 = rec[0], q1 = rec[1], q2 = rec[2];
+            // RayTriangleIntersect, RS:119-146
+            v3 edgeAB = V3(q1.x, q1.y, q1.z), edgeAC = V3(q2.x, q2.y, q2.z);
+            v3 normalVector = V3(q0.w, q1.w, q2.w);
+            v3 ao = s.rpos - V3(q0.x, q0.y, q0.z);
+            v3 dao = cross(ao, s.rdir);
+            float determinant = -dot(s.rdir, normalVector);
+            float invDet = 1 / determinant;
+            float dst = dot(ao, normalVector) * invDet;
+            float u = dot(edgeAC, dao) * invDet;
+            float v = -dot(edgeAB, dao) * invDet;
+            float w = 1 - u - v;
+            bool didHit = determinant >= 1E-8f && dst >= 0 && u >= 0 && v >= 0 && w >= 0;
+            t.triChecks++;
+            if (didHit && dst < s.best) { s.best = dst; s.localU = u; s.localV = v; s.localTri = triIndex; }
         }
     }
-    t.dst = s.worldBest;
+    travPop<INSTR>(P, s, t, stk);
+}
+// One outer trip for the lanes with `alive` set: service, internal-node phase, leaf phase.  Clears `alive` (and sets
+// t.dst) for lanes whose ray ends.
+template <bool INSTR, bool RIS>
+DEV void travTrip(const KParams& P, TravState& s, Trav& t, uint32_t* stk, bool& alive) {
+    if (alive && s.e == ENTRY_NONE) alive = travService<INSTR, RIS>(P, s, t, stk);
+    for (;;) {
+        const bool isInt = alive && s.e != ENTRY_NONE && (s.e & LEAF_BITS) == 0;
+        if (__builtin_amdgcn_ballot_w64(isInt) == 0) break;
+        if (isInt) travInternal<INSTR, RIS>(P, s, t, stk);
+        // leave the phase once at least half of the lanes still at work wait for a leaf or for service
+        const unsigned long long waitMask = __builtin_amdgcn_ballot_w64(alive && (s.e == ENTRY_NONE || (s.e & LEAF_BITS) != 0));
+        if (RT_LEAF_DEN * __builtin_popcountll(waitMask) >= RT_LEAF_NUM * __builtin_popcountll(__builtin_amdgcn_ballot_w64(alive))) break;
+    }
+    if (alive && s.e != ENTRY_NONE && (s.e & LEAF_BITS) != 0) travLeaf<INSTR, RIS>(P, s, t, stk);
 }
 
-// ---- third formulation: rare work moved out of the hot loop -----------------------------------------------------
-// Same visit order as traverse2, but leaving an object (RS:251-258), entering the next one (RS:235-246: two matrix
-// products and three IEEE divisions) and finishing the ray are no longer part of every trip of the internal-node
-// loop: a lane that needs one of them holds ENTRY_NONE and waits, and all such lanes are served together in a
-// "service" step once per outer trip.  With 64 lanes at different places in their trees, almost every trip of the
-// traverse2 loop had SOME lane on that path, so every trip paid for its ~200 instructions; a ray needs it only a
-// handful of times.  Taking the next entry from the stack stays inline (one LDS read).
 template <bool INSTR, bool RIS = false>
 DEV void traverse3(const KParams& P, const v3 wpos, const v3 wdir, const v3 winv, uint32_t* stk, Trav& t) {
     TravState s;
-    s.rpos = wpos; s.rdir = wdir; s.rinv = winv;
-    s.best = INF(); s.worldBest = INF();
-    s.sp = 0; s.objBase = -1; s.objCur = 0; s.objEnd = 0; s.curObj = -1; s.localTri = -1;
-    s.localU = 0; s.localV = 0;
-    t.tri = -1; t.obj = -1; t.u = 0; t.v = 0; t.triChecks = 0; t.bvChecks = 0;
-    if (INSTR) { t.hash = 2166136261u; t.pops = 1; t.objVisits = 0; t.triIters = 0; t.iters = 0; }
-    const int cap = P.stackDepth;
-    uint32_t e = P.sceneRootEntry;
+    travBegin<INSTR>(P, s, t, wpos, wdir, winv);
     bool alive = true;
-    constexpr uint32_t LEAF_BITS = ENTRY_LEAF | ENTRY_LEAF_INDIRECT;
-    // next entry of the level being traversed, or ENTRY_NONE when that level's part of the stack is used up
-    auto popInline = [&]() {
-        const int floor = s.objBase >= 0 ? s.objBase : 0;
-        if (s.sp > floor) {
-            --s.sp;
-            e = s.sp < cap ? stk[s.sp * 64] : ENTRY_LEAF;
-            if (INSTR) t.pops++;
-        } else {
-            e = ENTRY_NONE;
-        }
-    };
-    while (__builtin_amdgcn_ballot_w64(alive) != 0) {
-        // ---------- service: object exit / object entry / scene-level pop / end of ray ----------
-        if (alive && e == ENTRY_NONE) {
-            if (s.objBase >= 0) {  // the object's subtree is exhausted (RS:251-258)
-                if (s.best < s.worldBest) { s.worldBest = s.best; t.tri = s.localTri; t.obj = s.curObj; t.u = s.localU; t.v = s.localV; }
-                s.best = s.worldBest;
-                s.rpos = wpos; s.rdir = wdir; s.rinv = winv;
-                s.objBase = -1;
-            }
-            if (s.objCur < s.objEnd) {  // next scene object of the current scene-level leaf (RS:235-246)
-                const float* m = P.objs[s.objCur].worldToLocalMatrix.m;
-                s.rpos = mul44(m, wpos, 1.0f);
-                s.rdir = mul44(m, wdir, 0.0f);
-                if (!RIS) s.rinv = rcp3(s.rdir);
-                s.best = INF();
-                s.localTri = -1;
-                s.curObj = s.objCur;
-                s.objBase = s.sp;
-                e = P.objRootEntry[s.objCur];
-                s.objCur++;
-                if (INSTR) { t.objVisits++; t.pops++; }
-            } else if (s.sp == 0) {
-                alive = false;
-            } else {
-                --s.sp;
-                e = s.sp < cap ? stk[s.sp * 64] : ENTRY_LEAF;
-                if (INSTR) t.pops++;
-            }
-        }
-        // ---------- internal-node phase ----------
-        for (;;) {
-            const bool isInt = alive && e != ENTRY_NONE && (e & LEAF_BITS) == 0;
-            if (__builtin_amdgcn_ballot_w64(isInt) == 0) break;
-            if (isInt) {
-                if (INSTR) { t.iters++; t.hash = (t.hash ^ (0x80000000u | e)) * 16777619u; }
-                const float4* rec = P.wide + (int64_t)e * 4;
-                const float4 q0 = rec[0], q1 = rec[1], q2 = rec[2], q3 = rec[3];
-                const float dstA = RIS ? RayBVIntersectDiv(s.rpos, s.rdir, V3(q0.x, q0.y, q0.z), V3(q0.w, q1.x, q1.y))
-                                       : RayBVIntersect(s.rpos, s.rinv, V3(q0.x, q0.y, q0.z), V3(q0.w, q1.x, q1.y));
-                const float dstB = RIS ? RayBVIntersectDiv(s.rpos, s.rdir, V3(q1.z, q1.w, q2.x), V3(q2.y, q2.z, q2.w))
-                                       : RayBVIntersect(s.rpos, s.rinv, V3(q1.z, q1.w, q2.x), V3(q2.y, q2.z, q2.w));
-                t.bvChecks += 2;
-                const uint32_t eA = __float_as_uint(q3.x), eB = __float_as_uint(q3.y);
-                const bool aFirst = dstA < dstB;  // RS:204-214: the nearer child is visited first
-                const uint32_t eNear = aFirst ? eA : eB, eFar = aFirst ? eB : eA;
-                const bool nearHit = (aFirst ? dstA : dstB) < s.best, farHit = (aFirst ? dstB : dstA) < s.best;
-                if (nearHit) {
-                    if (farHit) { if (s.sp < cap) stk[s.sp * 64] = eFar; s.sp++; }
-                    e = eNear;
-                    if (INSTR) t.pops++;
-                } else if (farHit) {
-                    e = eFar;
-                    if (INSTR) t.pops++;
-                } else {
-                    popInline();
-                }
-            }
-            // leave the phase once at least half of the lanes still at work wait for a leaf or for service
-            const unsigned long long waitMask = __builtin_amdgcn_ballot_w64(alive && (e == ENTRY_NONE || (e & LEAF_BITS) != 0));
-            if (RT_LEAF_DEN * __builtin_popcountll(waitMask) >= RT_LEAF_NUM * __builtin_popcountll(__builtin_amdgcn_ballot_w64(alive))) break;
-        }
-        // ---------- leaf phase ----------
-        if (alive && e != ENTRY_NONE && (e & LEAF_BITS) != 0) {
-            int start, count;
-            if (e & ENTRY_LEAF) {
-                start = (int)(e & (uint32_t)ENTRY_INLINE_MAX_START);
-                count = (int)((e >> 26) & 31u);
-                if (INSTR) { t.hash = (t.hash ^ (uint32_t)start) * 16777619u; t.hash = (t.hash ^ (uint32_t)count) * 16777619u; }
-            } else {
-                const rt_bv* bv = &P.BVs[e & ENTRY_INDEX_MASK];
-                int a = bv->indexA, b = bv->indexB;
-                if (INSTR) { t.hash = (t.hash ^ (uint32_t)a) * 16777619u; t.hash = (t.hash ^ (uint32_t)b) * 16777619u; }
-                start = a < 0 ? -a : a;
-                count = b < 0 ? -b : b;
-            }
-            if (INSTR) t.iters++;
-            if (s.objBase < 0) {  // scene-level leaf: a run of scene objects, entered one by one by the service step
-                s.objCur = start;
-                s.objEnd = start + count;
-                e = ENTRY_NONE;
-            } else {
-                for (int triIndex = start; triIndex < start + count; triIndex++) {  // RS:179-193
-                    const float4* rec = P.btri + (int64_t)triIndex * 4;
-                    if (INSTR) t.triIters++;
-                    bool facing = true;
-                    if (!RIS) { const float4 q3 = rec[3]; facing = dot(V3(q3.x, q3.y, q3.z), s.rdir) <= 0; }
-                    if (facing) {
-                        const float4 q0 = rec[0], q1 = rec[1], q2 = rec[2];
-                        v3 edgeAB = V3(q1.x, q1.y, q1.z), edgeAC = V3(q2.x, q2.y, q2.z);
-                        v3 normalVector = V3(q0.w, q1.w, q2.w);
-                        v3 ao = s.rpos - V3(q0.x, q0.y, q0.z);
-                        v3 dao = cross(ao, s.rdir);
-                        float determinant = -dot(s.rdir, normalVector);
-                        float invDet = 1 / determinant;
-                        float dst = dot(ao, normalVector) * invDet;
-                        float u = dot(edgeAC, dao) * invDet;
-                        float v = -dot(edgeAB, dao) * invDet;
-                        float w = 1 - u - v;
-                        bool didHit = determinant >= 1E-8f && dst >= 0 && u >= 0 && v >= 0 && w >= 0;
-                        t.triChecks++;
-                        if (didHit && dst < s.best) { s.best = dst; s.localU = u; s.localV = v; s.localTri = triIndex; }
-                    }
-                }
-                popInline();
-            }
-        }
-    }
-    t.dst = s.worldBest;
+    while (__builtin_amdgcn_ballot_w64(alive) != 0) travTrip<INSTR, RIS>(P, s, t, stk, alive);
 }
 
 // Shading data of a traversal result, as TraverseSceneBVH leaves it in hitInfo (RS:248-258).
@@ -1057,6 +831,9 @@ __global__ __launch_bounds__(256, 5) void k_trace_rays(const KParams P) {
     uint32_t rays = 0, pops = 0, bvc = 0, objv = 0, trii = 0, tric = 0, iters = 0;
     unsigned long long tStart = 0;
     if (INSTR && P.waveProfile) tStart = wall_clock64();
+    // every lane's colour is stored once, after the wave has reconverged: lanes that take the short branches would
+    // otherwise write their part of a 128-byte line long before the tracing lanes do, and the line goes out twice
+    float4 colour = make_float4(0, 0, 0, 0);
     if (px.active) {
         const uint32_t idx = (uint32_t)px.x, idy = (uint32_t)px.y;
         uint32_t state = idy * (uint32_t)P.ResX + idx + P.FrameRand;
@@ -1066,11 +843,11 @@ __global__ __launch_bounds__(256, 5) void k_trace_rays(const KParams P) {
         const Reservoir cr = loadReservoir(P.cand, pixelIndex);
         if (hitInfo.dst == INF()) {
             v3 col = SampleEnvironmentMap(P, hitInfo.incomingDir);
-            P.result.rgba[i] = make_float4(col.x, col.y, col.z, 0.0f);
+            colour = make_float4(col.x, col.y, col.z, 0.0f);
         } else if ((cr.dir.x == 0 || cr.dir.y == 0 || cr.dir.z == 0) || dot(hitInfo.normal, cr.dir) < 0) {
             rt_material material = loadMaterial(P, hitInfo.materialIndex);
             v3 col = matCol(P, material, hitInfo.uv) * material.brightness / sqr(hitInfo.dst);
-            P.result.rgba[i] = make_float4(col.x, col.y, col.z, 0.0f);
+            colour = make_float4(col.x, col.y, col.z, 0.0f);
         } else {
             // Trace, RS:710-757.  ray.pos stays the primary hit point for every bounce, as in the reference.
             const v3 rpos = hitInfo.hitPoint;
@@ -1129,10 +906,11 @@ __global__ __launch_bounds__(256, 5) void k_trace_rays(const KParams P) {
             float correctionWeight = avgCandidateWeight / cr.chosenWeight;
             indirectLight = indirectLight * correctionWeight;
             v3 combined = directLight + (indirectLight / sqr(totTravelDst));
-            P.result.rgba[i] = make_float4(combined.x, combined.y, combined.z, 0.0f);
+            colour = make_float4(combined.x, combined.y, combined.z, 0.0f);
             if (INSTR && P.records && rays) P.records[i * RECORD_DWORDS + 7] = hash;
         }
     }
+    if (px.active) P.result.rgba[(int64_t)px.y * P.ResX + px.x] = colour;
     if (INSTR && P.waveProfile && P.waveProfileKernel == 2) writeWaveProfile(P, tStart, iters);
     if (P.stats) {
         waveAdd(P.stats + ST_RAYS, rays);

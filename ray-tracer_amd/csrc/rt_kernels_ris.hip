@@ -2,16 +2,10 @@
 //
 // What each kernel computes follows BVH_RIS_DL/Assets/Scripts/ComputeShaders/RIS_BVH_RayTracer.compute ("RI:line"),
 // RendererResources.hlsl ("RR:line") and PreCalc.compute of that project.  The traversal core, thread-to-pixel
-// mapping, LDS stack and counters are the ones of rt_kernels.hip (traverse2 with RIS = true); the reference's
+// mapping, LDS stack and counters are the ones of rt_kernels.hip (traverse3 with RIS = true); the reference's
 // GenerateCandidates kernel is split into a primary-ray kernel and a candidate kernel, as InitialTrace is.
 // Included by rt_native.hip after rt_kernels.hip (one translation unit).
 namespace rtn {
-
-#if RT_TRAVERSE_V == 3
-#define TRAVERSE_RIS traverse3
-#else
-#define TRAVERSE_RIS traverse2
-#endif
 
 DEV bool weightedRandRIS(float a, float b, uint32_t& state) {  // RR:85-92
     float randNorm = randNormalized(state);
@@ -98,7 +92,7 @@ __global__ __launch_bounds__(256, RT_MIN_WAVES) void k_ris_primary(const KParams
         const uint32_t rayIndex = ((uint32_t)P.ResX * idy + idx) * (uint32_t)P.RaysPerPixel;
         v3 rdir = normalize(worldFocalPos - cam);
 
-        TRAVERSE_RIS<INSTR, true>(P, cam, rdir, rdir, laneStack(lds, P.stackDepth), t);
+        traverse3<INSTR, true>(P, cam, rdir, rdir, laneStack(lds, P.stackDepth), t);
         rays = 1;
         const RisHit h = resolveRisHit(P, t, cam, rdir);
         const bool didHit = h.dst != INF();
@@ -272,7 +266,7 @@ __global__ __launch_bounds__(256, RT_MIN_WAVES) void k_ris_trace_rays(const KPar
                     rayColor = rayColor * lerp3(V3(material.color), V3(material.specularColor), isSpecularBounce ? 1.0f : 0.0f);
                     if (bounceCount != P.risMaxBounceCount) {
                         Trav t;
-                        TRAVERSE_RIS<INSTR, true>(P, rpos, rdir, rdir, laneStack(lds, P.stackDepth), t);
+                        traverse3<INSTR, true>(P, rpos, rdir, rdir, laneStack(lds, P.stackDepth), t);
                         rays++;
                         if (INSTR) {
                             pops += t.pops; bvc += (uint32_t)t.bvChecks; objv += t.objVisits; trii += t.triIters;
