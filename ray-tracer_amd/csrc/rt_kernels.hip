@@ -645,8 +645,8 @@ __global__ __launch_bounds__(256, RT_MIN_WAVES) void k_candidates(const KParams 
     if (px.active) {
         const uint32_t idx = (uint32_t)px.x, idy = (uint32_t)px.y;
         const int64_t i = (int64_t)idy * P.ResX + idx;
-        const HitInfo hitInfo = loadHit(P, i);
-        if (hitInfo.dst != INF()) {
+        if (P.hit.p0[i].w != INF()) {  // pixels whose primary ray missed need only this one plane
+            const HitInfo hitInfo = loadHit(P, i);
             // the two draws of randPointInCircle precede this in the reference's single kernel
             uint32_t state = idy * (uint32_t)P.ResX + idx + P.FrameRand;
             NextRandom(state);
@@ -781,7 +781,9 @@ __global__ __launch_bounds__(256) void k_spatial(const KParams P) {
             neighbours++;
             if (cand.dir.x == 0 || cand.dir.y == 0 || cand.dir.z == 0) continue;  // `all(dir) == 0`, RS:536
             float hitPointDiff = length(base.hitPoint - cand.hitPoint);
-            float normalDiffDeg = angleBetweenNormals(base.normal, cand.normal);
+            // acos never exceeds 180 degrees (and a NaN fails the comparison below like any angle within the
+            // threshold), so with a threshold above that the angle need not be evaluated
+            float normalDiffDeg = P.SpatialNormalsAngleThreshold > 181.0f ? 0.0f : angleBetweenNormals(base.normal, cand.normal);
             if (hitPointDiff > P.SpatialHitPointDiffThreshold || normalDiffDeg > P.SpatialNormalsAngleThreshold ||
                 rtdm::fabs_(sp.brdf - cand.brdf) > P.SpatialBRDFThreshold)
                 continue;
@@ -839,10 +841,13 @@ __global__ __launch_bounds__(256, 5) void k_trace_rays(const KParams P) {
         uint32_t state = idy * (uint32_t)P.ResX + idx + P.FrameRand;
         const uint32_t pixelIndex = (uint32_t)P.ResX * idy + idx;
         const int64_t i = (int64_t)idy * P.ResX + idx;
-        HitInfo hitInfo = loadHit(P, i);
-        const Reservoir cr = loadReservoir(P.cand, pixelIndex);
-        if (hitInfo.dst == INF()) {
-            v3 col = SampleEnvironmentMap(P, hitInfo.incomingDir);
+        HitInfo hitInfo;
+        hitInfo.dst = P.hit.p0[i].w;
+        Reservoir cr = emptyReservoir();
+        if (hitInfo.dst != INF()) { hitInfo = loadHit(P, i); cr = loadReservoir(P.cand, pixelIndex); }
+        if (hitInfo.dst == INF()) {  // a pixel whose primary ray missed needs only the incoming direction
+            const float4 c = P.hit.p2[i];
+            v3 col = SampleEnvironmentMap(P, V3(c.x, c.y, c.z));
             colour = make_float4(col.x, col.y, col.z, 0.0f);
         } else if ((cr.dir.x == 0 || cr.dir.y == 0 || cr.dir.z == 0) || dot(hitInfo.normal, cr.dir) < 0) {
             rt_material material = loadMaterial(P, hitInfo.materialIndex);
