@@ -20,7 +20,7 @@ $(PKG)/librtnative.so: $(PKG)/csrc/rt_native.hip $(PKG)/csrc/rt_kernels.hip $(PK
 	$(HIPCC) $(HIPFLAGS) -shared -o $@ $(PKG)/csrc/rt_native.hip
 
 $(PKG)/librthost.so: $(PKG)/host/scene_builder.cpp $(PKG)/host/frame_driver.cpp $(PKG)/host/ris_driver.cpp $(PKG)/host/scene_cache.cpp $(PKG)/host/scene_internal.h $(PKG)/host/rth_api.h $(PKG)/host/unity_math.h $(PKG)/host/unity_shim.h include/rt_native.h include/rt_types.h $(PKG)/librtnative.so
-	$(CXX) $(CXXFLAGS) -shared -o $@ $(PKG)/host/scene_builder.cpp $(PKG)/host/frame_driver.cpp $(PKG)/host/ris_driver.cpp $(PKG)/host/scene_cache.cpp -L$(PKG) -lrtnative -Wl,-rpath,'$$ORIGIN'
+	$(CXX) $(CXXFLAGS) -shared -o $@ $(PKG)/host/scene_builder.cpp $(PKG)/host/frame_driver.cpp $(PKG)/host/ris_driver.cpp $(PKG)/host/scene_cache.cpp -L$(PKG) -lrtnative -ldl -Wl,-rpath,'$$ORIGIN'
 
 clean:
 	rm -f $(PKG)/librtnative.so $(PKG)/librthost.so

@@ -92,6 +92,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-frames", type=int, default=2)
     ap.add_argument("--small-scene", action="store_true", help="8.7k-triangle dragon instead of the 78k stand-in")
+    ap.add_argument("--exchange", choices=("rccl", "torch"), default="rccl",
+                    help="N > 1: halo exchange from the C++ frame loop with RCCL calls (default), or from Python with "
+                         "torch.distributed's NCCL backend")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -110,7 +113,10 @@ def main():
 
     if world > 1:
         mg = importlib.import_module("ray-tracer_amd.multigpu")
-        runner = mg.DistributedRunner(rt, scene, cfg, rank, world, local_rank)
+        if args.exchange == "rccl":
+            runner = mg.RcclRunner(rt, scene, cfg, rank, world, local_rank)
+        else:
+            runner = mg.DistributedRunner(rt, scene, cfg, rank, world, local_rank)
     else:
         runner = SingleRunner(rt, scene, cfg)
 
@@ -173,7 +179,7 @@ def main():
             "config": {"workload": f"BVH_ReSTIR_DL 80kScene* ({'8.7k' if args.small_scene else '78k'}-triangle dragon stand-in "
                                    f"+ Suzanne light) {W}x{H}, temporal + 3 spatial reuse passes, VIS_REUSE+BRDF",
                        "resolution": [W, H], "triangles": int(len(scene.arrays()['Triangles'])),
-                       "parallelism": f"row-bands x{world}" if world > 1 else "single GPU",
+                       "parallelism": f"row-bands x{world} ({args.exchange} halo exchange)" if world > 1 else "single GPU",
                        "rays_per_frame": rays_total / args.steps},
             "roofline": roofline, "kernels": kernels,
         }

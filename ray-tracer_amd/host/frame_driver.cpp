@@ -385,3 +385,231 @@ rt_shader rth_main_shader(rth_main m, const char* name) {
 }
 
 }  // extern "C"
+
+// ==================================================================================================================
+// Multi-GPU frame loop: one process per GPU, the image cut into row bands, halos and the displayed image moved with
+// RCCL point-to-point transfers on the context's own stream.  The reference is single-GPU; this is the sharding the
+// path admits (every kernel reads only its own pixel except SpatialReusePass, which reads reservoirs and depths up to
+// MaxOffset + 1 rows away).  The schedule below is the one ray-tracer_amd/multigpu.py runs over torch.distributed
+// (and that the CPU tests check against the single-process result); here no Python runs between frames.
+// ==================================================================================================================
+#include <dlfcn.h>
+
+namespace {
+
+// The RCCL entry points used, resolved at run time so that the library loads on machines without RCCL.
+struct Rccl {
+    typedef struct ncclComm* comm_t;
+    struct UniqueId { char internal[128]; };
+    int (*GetUniqueId)(UniqueId*) = nullptr;
+    int (*CommInitRank)(comm_t*, int, UniqueId, int) = nullptr;
+    int (*CommDestroy)(comm_t) = nullptr;
+    int (*GroupStart)() = nullptr;
+    int (*GroupEnd)() = nullptr;
+    int (*Send)(const void*, size_t, int, int, comm_t, void*) = nullptr;
+    int (*Recv)(void*, size_t, int, int, comm_t, void*) = nullptr;
+    const char* (*GetErrorString)(int) = nullptr;
+    bool ok = false;
+    std::string why;
+    Rccl() {
+        void* h = nullptr;
+        for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"})
+            if ((h = dlopen(name, RTLD_NOW | RTLD_GLOBAL))) break;
+        if (!h) { why = "librccl.so could not be loaded"; return; }
+        auto sym = [&](const char* n) { void* p = dlsym(h, n); if (!p) why = std::string("RCCL symbol missing: ") + n; return p; };
+        GetUniqueId = (decltype(GetUniqueId))sym("ncclGetUniqueId");
+        CommInitRank = (decltype(CommInitRank))sym("ncclCommInitRank");
+        CommDestroy = (decltype(CommDestroy))sym("ncclCommDestroy");
+        GroupStart = (decltype(GroupStart))sym("ncclGroupStart");
+        GroupEnd = (decltype(GroupEnd))sym("ncclGroupEnd");
+        Send = (decltype(Send))sym("ncclSend");
+        Recv = (decltype(Recv))sym("ncclRecv");
+        GetErrorString = (decltype(GetErrorString))sym("ncclGetErrorString");
+        ok = why.empty();
+    }
+};
+Rccl& rccl() { static Rccl r; return r; }
+const int NCCL_UINT8 = 1;  // ncclUint8 / ncclChar share the value 1 and 0; bytes are bytes either way
+
+}  // namespace
+
+struct rth_mg_s {
+    rth_main m = nullptr;
+    int rank = 0, world = 1;
+    std::vector<int> bounds;
+    Rccl::comm_t comm = nullptr;
+    std::string err;
+};
+
+extern "C" {
+
+// Row boundaries b[0..world] of the bands: multiples of 8 rows (the tile height) except the last, heights as equal as
+// that allows.  Returns -1 if some band would be empty.
+int rth_mg_band_bounds(int height, int world, int* out) {
+    if (height < 1 || world < 1 || !out) return -1;
+    for (int r = 0; r < world; r++) out[r] = (int)nearbyint((double)height * r / world / 8.0) * 8;  // round half to even
+    out[world] = height;
+    for (int r = 0; r < world; r++) if (out[r + 1] <= out[r]) return -1;
+    return 0;
+}
+// Per spatial pass i (MaxOffset = 3^i * blur, Main.cs:394): halo[i] = rows the pass reads beyond the rows it writes
+// (MaxOffset down, MaxOffset up, one more up because a negative x offset wraps into the previous row), extend[i] =
+// rows it must write beyond the band so that the later passes find their inputs.  Returns the rows exchanged once
+// per frame (the sum of the halos).
+int rth_mg_halo_plan(int iterations, int blur, int* halo, int* extend) {
+    int total = 0;
+    std::vector<int> h((size_t)(iterations > 0 ? iterations : 0));
+    for (int i = 0; i < iterations; i++) { h[(size_t)i] = (int)(float)pow(3.0, (double)i) * blur + 1; total += h[(size_t)i]; }
+    int later = 0;
+    for (int i = iterations - 1; i >= 0; i--) {
+        if (halo) halo[i] = h[(size_t)i];
+        if (extend) extend[i] = later;
+        later += h[(size_t)i];
+    }
+    return total;
+}
+
+int rth_mg_unique_id(unsigned char out[128]) {
+    if (!out || !rccl().ok) return -1;
+    Rccl::UniqueId id;
+    if (rccl().GetUniqueId(&id) != 0) return -1;
+    memcpy(out, id.internal, 128);
+    return 0;
+}
+
+rth_mg rth_mg_create(rth_main m, int rank, int world, const unsigned char uniqueId[128], char* err, int errLen) {
+    auto fail = [&](const std::string& msg) { if (err && errLen > 0) snprintf(err, (size_t)errLen, "%s", msg.c_str()); return (rth_mg) nullptr; };
+    if (!m || world < 1 || rank < 0 || rank >= world) return fail("bad arguments");
+    rth_mg g = new rth_mg_s;
+    g->m = m; g->rank = rank; g->world = world;
+    g->bounds.resize((size_t)world + 1);
+    if (rth_mg_band_bounds(m->cfg.Resolution[1], world, g->bounds.data()) != 0) { delete g; return fail("the image cannot be cut into that many bands of whole tiles"); }
+    const int total = rth_mg_halo_plan(m->cfg.SpatialReuseIterations, m->cfg.SpatialReuseBlur, nullptr, nullptr);
+    for (int r = 0; r < world; r++)
+        if (world > 1 && g->bounds[(size_t)r + 1] - g->bounds[(size_t)r] < total) { delete g; return fail("a band is shorter than the halo: use fewer GPUs or a larger image"); }
+    if (world > 1 || uniqueId) {  // a communicator of one rank is legal (and lets a single GPU exercise the set-up)
+        if (!uniqueId) { delete g; return fail("a unique id is needed for more than one rank"); }
+        if (!rccl().ok) { std::string w = rccl().why; delete g; return fail(w); }
+        Rccl::UniqueId id;
+        memcpy(id.internal, uniqueId, 128);
+        int rc = rccl().CommInitRank(&g->comm, world, id, rank);  // on the device current in this thread (rt_create made it so)
+        if (rc != 0) { std::string w = std::string("ncclCommInitRank: ") + rccl().GetErrorString(rc); delete g; return fail(w); }
+    }
+    return g;
+}
+void rth_mg_destroy(rth_mg g) {
+    if (!g) return;
+    if (g->comm) { rt_sync(g->m->ctx); rccl().CommDestroy(g->comm); }
+    rt_set_row_band(g->m->ctx, 0, 0);
+    delete g;
+}
+const char* rth_mg_last_error(rth_mg g) { return g ? g->err.c_str() : "null"; }
+int rth_mg_bounds(rth_mg g, int* out) {
+    if (!g || !out) return -1;
+    for (size_t i = 0; i < g->bounds.size(); i++) out[i] = g->bounds[i];
+    return 0;
+}
+
+// Self-test of the transfer path on one rank: rows [src0, src1) of the Candidates buffer and of the depth texture are
+// sent to, and received from, this same rank with the RCCL calls the frame loop uses, landing at row dst0.
+int rth_mg_loopback(rth_mg g, int src0, int src1, int dst0) {
+    if (!g || !g->comm || src1 <= src0) return -1;
+    rth_main m = g->m;
+    rt_ctx ctx = m->ctx;
+    const int W = m->cfg.Resolution[0];
+    m->CreateTextures();
+    rt_segment a[5], b[5];
+    int na = 0, nb = 0;
+    if (rt_buffer_map_rows(m->CandidateBuffer.h, W, src0, src1, a, &na) < 0 || rt_texture_map_rows(m->DepthBufferTexture.h, src0, src1, &a[na]) < 0 ||
+        rt_buffer_map_rows(m->CandidateBuffer.h, W, dst0, dst0 + (src1 - src0), b, &nb) < 0 ||
+        rt_texture_map_rows(m->DepthBufferTexture.h, dst0, dst0 + (src1 - src0), &b[nb]) < 0 || na != nb) {
+        g->err = rt_last_error(ctx);
+        return -1;
+    }
+    int rc = rccl().GroupStart();
+    for (int k = 0; k <= na && rc == 0; k++) {
+        rc = rccl().Send(a[k].ptr, a[k].bytes, NCCL_UINT8, g->rank, g->comm, rt_stream(ctx));
+        if (rc == 0) rc = rccl().Recv(b[k].ptr, b[k].bytes, NCCL_UINT8, g->rank, g->comm, rt_stream(ctx));
+    }
+    int rc2 = rccl().GroupEnd();
+    if (rc != 0 || rc2 != 0) { g->err = std::string("RCCL loopback: ") + rccl().GetErrorString(rc != 0 ? rc : rc2); return -1; }
+    return 0;
+}
+
+// n banded frames, enqueued on the context's stream (asynchronous; rt_sync waits for them).
+int rth_mg_render_frames(rth_mg g, int n) {
+    if (!g) return -1;
+    rth_main m = g->m;
+    rt_ctx ctx = m->ctx;
+    void* stream = rt_stream(ctx);
+    const int rank = g->rank, world = g->world, H = m->cfg.Resolution[1], W = m->cfg.Resolution[0];
+    const int b0 = g->bounds[(size_t)rank], b1 = g->bounds[(size_t)rank + 1];
+    const int iterations = m->cfg.SpatialReuseIterations;
+    std::vector<int> halo((size_t)(iterations > 0 ? iterations : 1)), extend(halo.size());
+    const int total = rth_mg_halo_plan(iterations, m->cfg.SpatialReuseBlur, halo.data(), extend.data());
+    try {
+        auto check = [&](int rc, const char* what) { if (rc < 0) throw DriverError{std::string(what) + ": " + rt_last_error(ctx)}; };
+        auto nccl = [&](int rc, const char* what) { if (rc != 0) throw DriverError{std::string(what) + ": " + rccl().GetErrorString(rc)}; };
+        auto rows = [&](int r0, int r1) { check(rt_set_row_band(ctx, r0, r1), "rt_set_row_band"); };
+        // sends (or receives) rows [r0, r1) of the reservoir buffer `buf` and of the depth texture to (from) `peer`
+        auto moveRows = [&](bool send, rt_buffer buf, rt_texture tex, int r0, int r1, int peer) {
+            if (r1 <= r0) return;
+            rt_segment seg[5];
+            int cnt = 0;
+            if (buf) check(rt_buffer_map_rows(buf, W, r0, r1, seg, &cnt), "rt_buffer_map_rows");
+            if (tex) { check(rt_texture_map_rows(tex, r0, r1, &seg[cnt]), "rt_texture_map_rows"); cnt++; }
+            for (int k = 0; k < cnt; k++) {
+                if (send) nccl(rccl().Send(seg[k].ptr, seg[k].bytes, NCCL_UINT8, peer, g->comm, stream), "ncclSend");
+                else nccl(rccl().Recv(seg[k].ptr, seg[k].bytes, NCCL_UINT8, peer, g->comm, stream), "ncclRecv");
+            }
+        };
+        m->CreateTextures();
+        for (int f = 0; f < n; f++) {
+            rows(b0, b1);
+            m->UpdatePerFrame();
+            m->RunStage(0);
+            m->RunStage(1);
+            if (iterations > 0) {
+                if (world > 1) {
+                    // one exchange per frame: my border rows of the first pass's source buffer and of the depth buffer
+                    // go to both neighbours, theirs come here, `total` rows deep
+                    nccl(rccl().GroupStart(), "ncclGroupStart");
+                    if (rank > 0) {
+                        moveRows(true, m->CandidateBuffer.h, m->DepthBufferTexture.h, b0, b0 + total < b1 ? b0 + total : b1, rank - 1);
+                        moveRows(false, m->CandidateBuffer.h, m->DepthBufferTexture.h, b0 - total > 0 ? b0 - total : 0, b0, rank - 1);
+                    }
+                    if (rank < world - 1) {
+                        moveRows(true, m->CandidateBuffer.h, m->DepthBufferTexture.h, b1 - total > b0 ? b1 - total : b0, b1, rank + 1);
+                        moveRows(false, m->CandidateBuffer.h, m->DepthBufferTexture.h, b1, b1 + total < H ? b1 + total : H, rank + 1);
+                    }
+                    nccl(rccl().GroupEnd(), "ncclGroupEnd");
+                }
+                for (int i = 0; i < iterations; i++) {
+                    // the earlier passes also write the rows the later passes will read from beyond the band
+                    int lo = rank > 0 ? b0 - extend[(size_t)i] : b0, hi = rank < world - 1 ? b1 + extend[(size_t)i] : b1;
+                    rows(lo > 0 ? lo : 0, hi < H ? hi : H);
+                    m->SpatialReusePass(i);
+                }
+                rows(b0, b1);
+                m->TransferIfNeeded();
+            }
+            m->RunStage(3);
+            m->RunPostProcessingShader();
+            if (world > 1) {  // the displayed image is completed on rank 0
+                nccl(rccl().GroupStart(), "ncclGroupStart");
+                if (rank == 0) {
+                    for (int r = 1; r < world; r++) moveRows(false, nullptr, m->RTResultTexture.h, g->bounds[(size_t)r], g->bounds[(size_t)r + 1], r);
+                } else {
+                    moveRows(true, nullptr, m->RTResultTexture.h, b0, b1, 0);
+                }
+                nccl(rccl().GroupEnd(), "ncclGroupEnd");
+            }
+        }
+    } catch (const DriverError& e) {
+        g->err = e.msg;
+        return -1;
+    }
+    return 0;
+}
+
+}  // extern "C"

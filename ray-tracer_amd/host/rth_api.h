@@ -148,6 +148,29 @@ rt_buffer rth_main_buffer(rth_main m, const char* name);
 rt_texture rth_main_texture(rth_main m, const char* name);
 rt_shader rth_main_shader(rth_main m, const char* name); /* "rt", "pp", "pc" */
 
+/* ------------------------------------------- multi-GPU frame loop --------------------------------------- */
+/* One process per GPU; the image is cut into row bands (rt_set_row_band), the scene replicated, reservoir/depth
+ * halos exchanged once per frame and the displayed image completed on rank 0 with RCCL point-to-point transfers on
+ * the context's stream.  No counterpart in the reference, which is single-GPU. */
+typedef struct rth_mg_s* rth_mg;
+/* Band boundaries b[0..world] (multiples of 8 rows except the last).  -1 if a band would be empty. */
+int rth_mg_band_bounds(int height, int world, int* out);
+/* halo[i] / extend[i] per spatial pass (see the definition); returns the rows exchanged per frame. */
+int rth_mg_halo_plan(int iterations, int blur, int* halo, int* extend);
+/* ncclGetUniqueId on the calling rank; the 128 bytes must reach every rank (any side channel) before rth_mg_create. */
+int rth_mg_unique_id(unsigned char out[128]);
+/* Collective over all ranks (ncclCommInitRank) when world > 1; world == 1 needs no id and no RCCL.  `m` must have
+ * been created on a context of this rank's GPU with full-frame buffers (row0 = row1 = 0). */
+rth_mg rth_mg_create(rth_main m, int rank, int world, const unsigned char uniqueId[128], char* err, int errLen);
+void rth_mg_destroy(rth_mg g);
+const char* rth_mg_last_error(rth_mg g);
+int rth_mg_bounds(rth_mg g, int* out);
+/* Self-test: moves rows [src0, src1) of Candidates and DepthBuffer to row dst0 through RCCL send/recv addressed to
+ * this same rank (needs a communicator, i.e. a unique id at creation). */
+int rth_mg_loopback(rth_mg g, int src0, int src1, int dst0);
+/* Enqueues n banded frames (asynchronous).  After rt_sync, rank 0's Result texture holds the whole image. */
+int rth_mg_render_frames(rth_mg g, int n);
+
 /* ------------------------------------- frame driver of the RIS project ---------------------------------- */
 typedef struct rth_ris_main_s* rth_ris_main;
 

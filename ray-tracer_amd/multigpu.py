@@ -249,3 +249,95 @@ class DistributedRunner:
         self.ctx.close()
         if dist.is_initialized():
             dist.destroy_process_group()
+
+
+# ---------------------------------------------------------------------------------- native (C++ + RCCL) frame loop
+def native_band_bounds(height, world):
+    """rth_mg_band_bounds: the C++ twin of band_bounds (equal-height bands)."""
+    import ctypes as C
+    import importlib
+    host = importlib.import_module("ray-tracer_amd").host_lib()
+    out = (C.c_int * (world + 1))()
+    if host.rth_mg_band_bounds(height, world, out) != 0:
+        raise ValueError(f"image of {height} rows cannot be cut into {world} non-empty bands of whole tiles")
+    return list(out)
+
+
+def native_halo_plan(iterations, blur):
+    """rth_mg_halo_plan: the C++ twin of halo_plan."""
+    import ctypes as C
+    import importlib
+    host = importlib.import_module("ray-tracer_amd").host_lib()
+    n = max(iterations, 1)
+    halo, extend = (C.c_int * n)(), (C.c_int * n)()
+    total = host.rth_mg_halo_plan(iterations, blur, halo, extend)
+    return list(halo)[:iterations], list(extend)[:iterations], total
+
+
+class RcclRunner:
+    """One rank of the native multi-GPU frame loop (host/frame_driver.cpp: rth_mg_*): the banded schedule above, run
+    from C++ with RCCL send/recv on the library's stream, so no Python runs between the dispatches of a frame.
+    torch.distributed (gloo) is only the side channel that carries the RCCL unique id and the timing reductions."""
+
+    def __init__(self, rt, scene, cfg, rank, world, local_rank, force_comm=False):
+        import ctypes as C
+        self.rt, self.rank, self.world = rt, rank, world
+        self.host = rt.host_lib()
+        self.ctx = rt.RtContext(local_rank)
+        self.drv = rt.Driver(self.ctx, cfg, scene)
+        self.W, self.H = cfg.Resolution[0], cfg.Resolution[1]
+        uid = None
+        if world > 1 or force_comm:
+            buf = C.create_string_buffer(128)
+            if rank == 0 and self.host.rth_mg_unique_id(buf) != 0:
+                raise RuntimeError("ncclGetUniqueId failed (is librccl.so loadable?)")
+            uid = buf.raw
+            if world > 1:
+                if not dist.is_initialized():
+                    dist.init_process_group("gloo", rank=rank, world_size=world)
+                box = [uid]
+                dist.broadcast_object_list(box, src=0)
+                uid = box[0]
+        err = C.create_string_buffer(512)
+        self.h = self.host.rth_mg_create(self.drv.h, rank, world, uid, err, 512)
+        if not self.h:
+            raise RuntimeError("rth_mg_create: " + err.value.decode())
+        b = (C.c_int * (world + 1))()
+        self.host.rth_mg_bounds(self.h, b)
+        self.bounds = list(b)
+
+    def render_frames(self, n):
+        if self.host.rth_mg_render_frames(self.h, n) != 0:
+            raise RuntimeError("rth_mg_render_frames: " + self.host.rth_mg_last_error(self.h).decode())
+
+    def render_frame(self):
+        self.render_frames(1)
+
+    def sync(self):
+        self.ctx.sync()
+
+    def barrier(self):
+        if self.world > 1:
+            dist.barrier()
+
+    def reduce(self, seconds, rays):
+        """(max over ranks of seconds, sum over ranks of rays)"""
+        if self.world == 1:
+            return seconds, rays
+        t = torch.tensor([seconds], dtype=torch.float64)
+        r = torch.tensor([rays], dtype=torch.int64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dist.all_reduce(r, op=dist.ReduceOp.SUM)
+        return float(t[0]), int(r[0])
+
+    def band_pixels(self):
+        return (self.bounds[self.rank + 1] - self.bounds[self.rank]) * self.W
+
+    def close(self):
+        if self.h:
+            self.host.rth_mg_destroy(self.h)
+            self.h = None
+        self.drv.close()
+        self.ctx.close()
+        if self.world > 1 and dist.is_initialized():
+            dist.destroy_process_group()

@@ -114,3 +114,22 @@ def test_band_bounds_and_halo():
     w[400:800] = 1.0                      # all the cost in the middle rows
     bw = mg.band_bounds(1080, 4, weights=w)
     assert bw[1] >= 400 and bw[3] <= 800  # cost-balanced cuts fall inside the expensive region
+
+
+def test_native_plan_matches_python():
+    """The C++ frame loop (rth_mg_*) computes its bands and halos with its own code: it must agree with the Python
+    schedule that the gloo tests above validate."""
+    mg = importlib.import_module("ray-tracer_amd.multigpu")
+    for height in (64, 96, 270, 1080, 1088, 2160, 4320):
+        for world in (1, 2, 3, 4, 5, 7, 8):
+            try:
+                want = mg.band_bounds(height, world)
+            except ValueError:
+                with pytest.raises(ValueError):
+                    mg.native_band_bounds(height, world)
+                continue
+            assert mg.native_band_bounds(height, world) == want, (height, world)
+    for iterations in range(0, 5):
+        for blur in (1, 2, 3, 5):
+            halos, extend, total = mg.halo_plan(iterations, blur)
+            assert mg.native_halo_plan(iterations, blur) == (halos, extend, total), (iterations, blur)
