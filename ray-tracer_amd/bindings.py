@@ -185,7 +185,7 @@ def host_lib():
             "rth_main_frame_count": (ci, [vp]), "rth_main_buffer": (vp, [vp, cs]), "rth_main_texture": (vp, [vp, cs]),
             "rth_main_shader": (vp, [vp, cs]),
             "rth_mg_band_bounds": (ci, [ci, ci, C.POINTER(ci)]), "rth_mg_halo_plan": (ci, [ci, ci, C.POINTER(ci), C.POINTER(ci)]),
-            "rth_mg_unique_id": (ci, [C.c_char_p]), "rth_mg_create": (vp, [vp, ci, ci, C.c_char_p, C.c_char_p, ci]),
+            "rth_mg_unique_id": (ci, [C.c_char_p]), "rth_mg_create": (vp, [vp, ci, ci, C.POINTER(ci), C.c_char_p, C.c_char_p, ci]),
             "rth_mg_destroy": (None, [vp]), "rth_mg_last_error": (cs, [vp]), "rth_mg_bounds": (ci, [vp, C.POINTER(ci)]),
             "rth_mg_render_frames": (ci, [vp, ci]), "rth_mg_loopback": (ci, [vp, ci, ci, ci]),
             "rth_ris_default_config": (None, [C.POINTER(RisConfig)]), "rth_ris_camera_transform": (None, [fp, fp]),

@@ -477,13 +477,18 @@ int rth_mg_unique_id(unsigned char out[128]) {
     return 0;
 }
 
-rth_mg rth_mg_create(rth_main m, int rank, int world, const unsigned char uniqueId[128], char* err, int errLen) {
+rth_mg rth_mg_create(rth_main m, int rank, int world, const int* bounds, const unsigned char uniqueId[128], char* err, int errLen) {
     auto fail = [&](const std::string& msg) { if (err && errLen > 0) snprintf(err, (size_t)errLen, "%s", msg.c_str()); return (rth_mg) nullptr; };
     if (!m || world < 1 || rank < 0 || rank >= world) return fail("bad arguments");
     rth_mg g = new rth_mg_s;
     g->m = m; g->rank = rank; g->world = world;
     g->bounds.resize((size_t)world + 1);
-    if (rth_mg_band_bounds(m->cfg.Resolution[1], world, g->bounds.data()) != 0) { delete g; return fail("the image cannot be cut into that many bands of whole tiles"); }
+    if (bounds) {  // the caller's cuts (e.g. balanced by cost); every rank must pass the same ones
+        for (int r = 0; r <= world; r++) g->bounds[(size_t)r] = bounds[r];
+        bool ok = bounds[0] == 0 && bounds[world] == m->cfg.Resolution[1];
+        for (int r = 0; r < world; r++) ok = ok && bounds[r + 1] > bounds[r] && (bounds[r] % 8 == 0);
+        if (!ok) { delete g; return fail("band boundaries must start at 0, end at the image height, increase, and be multiples of 8"); }
+    } else if (rth_mg_band_bounds(m->cfg.Resolution[1], world, g->bounds.data()) != 0) { delete g; return fail("the image cannot be cut into that many bands of whole tiles"); }
     const int total = rth_mg_halo_plan(m->cfg.SpatialReuseIterations, m->cfg.SpatialReuseBlur, nullptr, nullptr);
     for (int r = 0; r < world; r++)
         if (world > 1 && g->bounds[(size_t)r + 1] - g->bounds[(size_t)r] < total) { delete g; return fail("a band is shorter than the halo: use fewer GPUs or a larger image"); }

@@ -159,9 +159,10 @@ int rth_mg_band_bounds(int height, int world, int* out);
 int rth_mg_halo_plan(int iterations, int blur, int* halo, int* extend);
 /* ncclGetUniqueId on the calling rank; the 128 bytes must reach every rank (any side channel) before rth_mg_create. */
 int rth_mg_unique_id(unsigned char out[128]);
-/* Collective over all ranks (ncclCommInitRank) when world > 1; world == 1 needs no id and no RCCL.  `m` must have
+/* bounds: band boundaries b[0..world] every rank agrees on, or NULL for rth_mg_band_bounds' equal heights.
+ * Collective over all ranks (ncclCommInitRank) when world > 1; world == 1 needs no id and no RCCL.  `m` must have
  * been created on a context of this rank's GPU with full-frame buffers (row0 = row1 = 0). */
-rth_mg rth_mg_create(rth_main m, int rank, int world, const unsigned char uniqueId[128], char* err, int errLen);
+rth_mg rth_mg_create(rth_main m, int rank, int world, const int* bounds, const unsigned char uniqueId[128], char* err, int errLen);
 void rth_mg_destroy(rth_mg g);
 const char* rth_mg_last_error(rth_mg g);
 int rth_mg_bounds(rth_mg g, int* out);

@@ -20,24 +20,37 @@ import torch
 import torch.distributed as dist
 
 
-def band_bounds(height, world, weights=None):
+def band_bounds(height, world, weights=None, min_rows=8):
     """Row boundaries b[0..world] of the bands, each a multiple of 8 (the tile height) except the last.
 
-    weights: optional per-row cost estimate; bands then get roughly equal cost instead of equal height."""
+    weights: optional per-row cost estimate; bands then get roughly equal cost instead of equal height, but never
+    fewer than min_rows rows (a band must be at least as tall as the halo its neighbours take from it)."""
     if weights is None:
         cuts = [round(height * r / world / 8) * 8 for r in range(world)] + [height]
     else:
         import numpy as np
+        min_rows = -(-max(min_rows, 8) // 8) * 8
         c = np.concatenate([[0.0], np.cumsum(np.asarray(weights, dtype=np.float64))])
         cuts = [0]
         for r in range(1, world):
             row = int(np.searchsorted(c, c[-1] * r / world))
-            cuts.append(min(height, max(cuts[-1] + 8, round(row / 8) * 8)))
+            cut = max(cuts[-1] + min_rows, round(row / 8) * 8)
+            cut = min(cut, (height - (world - r) * min_rows) // 8 * 8)      # leave room for the bands below
+            cuts.append(cut)
         cuts.append(height)
     for a, b in zip(cuts, cuts[1:]):
         if b <= a:
             raise ValueError(f"image of {height} rows cannot be cut into {world} non-empty bands of whole tiles")
     return cuts
+
+
+def row_cost(depth, hit_cost=24.0):
+    """Per-row cost estimate from a rendered depth buffer: every pixel costs one unit (the streaming work), a pixel
+    whose primary ray hit geometry `hit_cost` more (its shadow and light rays and the reuse passes).  The ratio is
+    the one measured on the 80kScene stand-in at 1080p (0.09 ns per pixel, 2.2 ns per hit pixel)."""
+    import numpy as np
+    hits = np.isfinite(np.asarray(depth)).sum(axis=1).astype(np.float64)
+    return depth.shape[1] + hit_cost * hits
 
 
 def spatial_halo(max_offset):
@@ -279,13 +292,22 @@ class RcclRunner:
     from C++ with RCCL send/recv on the library's stream, so no Python runs between the dispatches of a frame.
     torch.distributed (gloo) is only the side channel that carries the RCCL unique id and the timing reductions."""
 
-    def __init__(self, rt, scene, cfg, rank, world, local_rank, force_comm=False):
+    def __init__(self, rt, scene, cfg, rank, world, local_rank, force_comm=False, balance=True):
         import ctypes as C
         self.rt, self.rank, self.world = rt, rank, world
         self.host = rt.host_lib()
         self.ctx = rt.RtContext(local_rank)
         self.drv = rt.Driver(self.ctx, cfg, scene)
         self.W, self.H = cfg.Resolution[0], cfg.Resolution[1]
+        bounds = None
+        if balance and world > 1:
+            # Frame 0 is rendered in full by every rank: all ranks then hold the same depth buffer, derive the same
+            # per-row cost from it and so agree on cost-balanced bands without exchanging anything; the frames that
+            # follow are banded and continue the same sequence a single GPU would render.
+            self.drv.render_frame()
+            self.ctx.sync()
+            _, _, total = halo_plan(cfg.SpatialReuseIterations, cfg.SpatialReuseBlur)
+            bounds = band_bounds(self.H, world, row_cost(self.drv.texture("DepthBuffer")), min_rows=total)
         uid = None
         if world > 1 or force_comm:
             buf = C.create_string_buffer(128)
@@ -299,7 +321,8 @@ class RcclRunner:
                 dist.broadcast_object_list(box, src=0)
                 uid = box[0]
         err = C.create_string_buffer(512)
-        self.h = self.host.rth_mg_create(self.drv.h, rank, world, uid, err, 512)
+        cb = (C.c_int * (world + 1))(*bounds) if bounds else None
+        self.h = self.host.rth_mg_create(self.drv.h, rank, world, cb, uid, err, 512)
         if not self.h:
             raise RuntimeError("rth_mg_create: " + err.value.decode())
         b = (C.c_int * (world + 1))()

@@ -114,6 +114,14 @@ def test_band_bounds_and_halo():
     w[400:800] = 1.0                      # all the cost in the middle rows
     bw = mg.band_bounds(1080, 4, weights=w)
     assert bw[1] >= 400 and bw[3] <= 800  # cost-balanced cuts fall inside the expensive region
+    # a minimum height (the halo) is respected at both ends even when all the cost sits in a few rows
+    w = np.zeros(1080)
+    w[1000:1010] = 1.0
+    bw = mg.band_bounds(1080, 8, weights=w, min_rows=42)
+    assert all(b - a >= 48 for a, b in zip(bw, bw[1:-1])) and bw[-1] - bw[-2] >= 42 and all(x % 8 == 0 for x in bw[:-1])
+    depth = np.full((16, 10), np.inf, np.float32)
+    depth[4:8, :5] = 1.0
+    assert list(mg.row_cost(depth, 2.0)) == [10.0] * 4 + [20.0] * 4 + [10.0] * 8
 
 
 def test_native_plan_matches_python():
