@@ -51,11 +51,11 @@ def algorithmic_bytes(kernel, c, npx_launch):
     return 0
 
 
-def pmc_traffic(kernel, W, H, world, small_scene):
+def pmc_traffic(kernel, W, H, world, small_scene, scene="80k"):
     """HBM bytes per launch of `kernel` from the committed PMC passes (FETCH_SIZE and WRITE_SIZE, one rocprofv3 --pmc
     run each over this same command; tools/pmc_pass.sh, tools/pmc_to_traffic.py), or None when this run is not the
     configuration they were collected on.  Counters cannot be read from inside the process being timed."""
-    if (W, H, world, small_scene) != (1920, 1080, 1, False):
+    if (W, H, world, small_scene, scene) != (1920, 1080, 1, False, "80k"):
         return None
     path = os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")
     if not os.path.exists(path):
@@ -92,6 +92,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-frames", type=int, default=2)
     ap.add_argument("--small-scene", action="store_true", help="8.7k-triangle dragon instead of the 78k stand-in")
+    ap.add_argument("--scene", choices=("80k", "instanced"), default="80k",
+                    help="instanced: 16x8 instances of the 78k dragon (10 M triangles through one shared mesh BVH) lit by "
+                         "10 discs of 1000 emissive triangles: the deep-BVH configuration")
     ap.add_argument("--exchange", choices=("rccl", "torch"), default="rccl",
                     help="N > 1: halo exchange from the C++ frame loop with RCCL calls (default), or from Python with "
                          "torch.distributed's NCCL backend")
@@ -106,7 +109,11 @@ def main():
         args.gpus = world
 
     rt = importlib.import_module("ray-tracer_amd")
-    scene = rt.build_scene_s0(subdivide=not args.small_scene)
+    if args.scene == "instanced":
+        scene = rt.build_scene_instanced(grid=(16, 8), emissive_objects=10, emissive_tris=1000, unique=False,
+                                         subdivide=not args.small_scene)
+    else:
+        scene = rt.build_scene_s0(subdivide=not args.small_scene)
     cfg = rt.default_config()
     cfg.Resolution[0], cfg.Resolution[1] = args.width, args.height
     W, H = args.width, args.height
@@ -169,15 +176,19 @@ def main():
             d = timed[dominant]
             roofline = {"bound": "hbm", "kernel": dominant, "achieved": d["achieved_GBs"], "peak": HBM_PEAK_GBS,
                         "unit": "GB/s", "frac": d["achieved_GBs"] / HBM_PEAK_GBS,
-                        "traffic": pmc_traffic(dominant, W, H, world, args.small_scene),
+                        "traffic": pmc_traffic(dominant, W, H, world, args.small_scene, args.scene),
                         "avg_launch_ms": d["avg_ms"], "algorithmic_MB_per_launch": d["algorithmic_MB_per_launch"]}
         out = {
             "metric": "Mrays/s (primary+shadow) ReSTIR DL, 80kScene 1080p",
             "value": rays_total / 1e6 / dt_max, "unit": "Mrays/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": dt_max / args.steps * 1e3, "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"BVH_ReSTIR_DL 80kScene* ({'8.7k' if args.small_scene else '78k'}-triangle dragon stand-in "
-                                   f"+ Suzanne light) {W}x{H}, temporal + 3 spatial reuse passes, VIS_REUSE+BRDF",
+            "config": {"workload": (f"BVH_ReSTIR_DL 80kScene* ({'8.7k' if args.small_scene else '78k'}-triangle dragon stand-in "
+                                    f"+ Suzanne light)" if args.scene == "80k" else
+                                    "BVH_ReSTIR_DL instanced 80kScene* (128 dragon instances + 10 emissive discs)") +
+                                   f" {W}x{H}, temporal + 3 spatial reuse passes, VIS_REUSE+BRDF",
+                       "instanced_triangles": int(sum(scene.arrays()["ComponentDatas"][o["bvStartIndex"]][1]
+                                                      for o in scene.arrays()["SceneObjects"])),
                        "resolution": [W, H], "triangles": int(len(scene.arrays()['Triangles'])),
                        "parallelism": f"row-bands x{world} ({args.exchange} halo exchange)" if world > 1 else "single GPU",
                        "rays_per_frame": rays_total / args.steps},

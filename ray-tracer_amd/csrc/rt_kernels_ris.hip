@@ -132,10 +132,12 @@ __global__ __launch_bounds__(256, RT_MIN_WAVES) void k_ris_primary(const KParams
 // light samples per hit pixel.  No ray is cast here.  The primary ray draws no random numbers, so the RNG state
 // starts from the pixel's seed exactly as it does in the reference's single kernel.
 // =====================================================================================================
-DEV float risTriArea(const rt_ris_tri& tri) {  // GetTriArea, RR:117-124
-    v3 ab = V3(tri.vB) - V3(tri.vA);
-    v3 ac = V3(tri.vC) - V3(tri.vA);
-    return length(cross(ab, ac)) * 0.5f;
+// GetTriArea (RR:117-124) = length(cross(vB - vA, vC - vA)) * 0.5.  The cross product is the N of the baked triangle,
+// so the area is computed once per triangle when the scene is baked (same operations, same bits) and the two or
+// more area look-ups per candidate read 4 bytes instead of a 76-byte triangle.
+DEV float risTriArea(const KParams& P, int i) {
+    if (i < 0 || (int64_t)i >= P.nTris) return 0.0f;  // an all-zero triangle has area 0
+    return P.btri[(int64_t)i * 4 + 3].x;
 }
 DEV int risSceneObjectReservoirSample(const KParams& P, uint32_t& state) {  // RI:273-293
     int firstIndex = randIntSpan(0, P.risEmittingObjectsNum, state);
@@ -152,52 +154,88 @@ DEV int risSceneObjectReservoirSample(const KParams& P, uint32_t& state) {  // R
 DEV int risTriReservoirSample(const KParams& P, int startTriIndex, int endTriIndex, uint32_t& state) {  // RI:295-315
     int firstIndex = randIntSpan(startTriIndex, endTriIndex, state);
     int chosenIndex = firstIndex;
-    float totWeights = risTriArea(loadRisTri(P, firstIndex));
+    float totWeights = risTriArea(P, firstIndex);
     for (int i = 0; i < P.risTriReservoirTestsNum; i++) {
         int candidateIndex = randIntSpan(startTriIndex, endTriIndex, state);
-        float candidateWeight = risTriArea(loadRisTri(P, candidateIndex));
+        float candidateWeight = risTriArea(P, candidateIndex);
         if (weightedRandRIS(candidateWeight, totWeights, state)) chosenIndex = candidateIndex;
         totWeights += candidateWeight;
     }
     return chosenIndex;
 }
 
+// A pixel's candidates are 16 bytes each, Tot of them in a row: written straight from the lane that computes them, a
+// wave's 64 stores land 16*Tot bytes apart and every 128-byte line leaves the L2 partly filled several times.  So the
+// wave stages 8 candidates per pixel in LDS and then writes them out 8 lanes per pixel: whole 128-byte runs.
+constexpr int RIS_STAGE = 8;                   // candidates staged per pixel
+constexpr int RIS_STAGE_ROW = RIS_STAGE + 1;   // float4s per staged pixel (one of padding: spreads the LDS banks)
 __global__ __launch_bounds__(256) void k_ris_candidates(const KParams P) {
+    __shared__ float4 stageAll[WAVES_PER_BLOCK * 64 * RIS_STAGE_ROW];
+    __shared__ int baseAll[WAVES_PER_BLOCK * 64];
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float4* stage = stageAll + wave * 64 * RIS_STAGE_ROW;
+    int* rowBase = baseAll + wave * 64;
     const Pixel px = pixelOfThread(P);
     uint32_t generated = 0;
+    const uint32_t idx = (uint32_t)px.x, idy = (uint32_t)px.y;
+    const uint32_t rayIndex = ((uint32_t)P.ResX * idy + idx) * (uint32_t)P.RaysPerPixel;
+    RisHit h;
+    bool hit = false;
     if (px.active) {
-        const uint32_t idx = (uint32_t)px.x, idy = (uint32_t)px.y;
-        const uint32_t rayIndex = ((uint32_t)P.ResX * idy + idx) * (uint32_t)P.RaysPerPixel;
-        const RisHit h = loadRisHit(P, (int64_t)rayIndex);
-        if ((int64_t)rayIndex < P.nRisHit && h.dst != INF()) {
-            uint32_t state = idy * (uint32_t)P.ResX + idx + (uint32_t)P.risFrameRand;
-            for (int i = 0; i < P.SceneObjectCandidatesNum; i++) {
+        h = loadRisHit(P, (int64_t)rayIndex);
+        hit = (int64_t)rayIndex < P.nRisHit && h.dst != INF();
+    }
+    if (__builtin_amdgcn_ballot_w64(hit) != 0) {  // wave-uniform: the loops below are walked by the whole wave
+        uint32_t state = idy * (uint32_t)P.ResX + idx + (uint32_t)P.risFrameRand;
+        for (int i = 0; i < P.SceneObjectCandidatesNum; i++) {
+            rt_light_object lightObject;
+            int startTriIndex = 0, endTriIndex = 0;
+            if (hit) {
                 const int lightObjectIndex = risSceneObjectReservoirSample(P, state);
-                const rt_light_object lightObject = loadLight(P, lightObjectIndex);
-                const int startTriIndex = lightObject.triStart;
-                const int endTriIndex = lightObject.triStart + lightObject.totTris;
-                for (int j = 0; j < P.TriCandidatesNum; j++) {
-                    const int triIndex = risTriReservoirSample(P, startTriIndex, endTriIndex, state);
-                    const rt_ris_tri tri = loadRisTri(P, triIndex);
-                    // GetRandWorldPointTri, RR:126-143
-                    float r1 = randNormalized(state);
-                    float r2 = randNormalized(state);
-                    if (r1 + r2 > 1.0f) { r1 = 1.0f - r1; r2 = 1.0f - r2; }
-                    v3 localPoint = V3(tri.vA) * (1.0f - r1 - r2) + V3(tri.vB) * r1 + V3(tri.vC) * r2;
-                    v3 worldPoint = mul44(lightObject.localToWorldMatrix.m, localPoint, 1.0f);
-                    v3 dst = worldPoint - h.hitPoint;
-                    v3 dir = normalize(dst);
-                    const int candidateIndex = (int)rayIndex * P.TotCandidatesNum + i * P.TriCandidatesNum + j;
-                    generated++;
-                    if (dot(h.normal, dir) < 0) {
-                        storeRisCandidate(P, candidateIndex, make_float4(0, 0, 0, 0));
-                        continue;
+                lightObject = loadLight(P, lightObjectIndex);
+                startTriIndex = lightObject.triStart;
+                endTriIndex = lightObject.triStart + lightObject.totTris;
+            }
+            for (int j0 = 0; j0 < P.TriCandidatesNum; j0 += RIS_STAGE) {
+                const int nj = P.TriCandidatesNum - j0 < RIS_STAGE ? P.TriCandidatesNum - j0 : RIS_STAGE;
+                // index of this pixel's candidate j0 of light i, or -1 if the pixel generates none
+                rowBase[lane] = hit ? (int)rayIndex * P.TotCandidatesNum + i * P.TriCandidatesNum + j0 : -1;
+                if (hit) {
+                    for (int jj = 0; jj < nj; jj++) {
+                        const int triIndex = risTriReservoirSample(P, startTriIndex, endTriIndex, state);
+                        const rt_ris_tri tri = loadRisTri(P, triIndex);
+                        // GetRandWorldPointTri, RR:126-143
+                        float r1 = randNormalized(state);
+                        float r2 = randNormalized(state);
+                        if (r1 + r2 > 1.0f) { r1 = 1.0f - r1; r2 = 1.0f - r2; }
+                        v3 localPoint = V3(tri.vA) * (1.0f - r1 - r2) + V3(tri.vB) * r1 + V3(tri.vC) * r2;
+                        v3 worldPoint = mul44(lightObject.localToWorldMatrix.m, localPoint, 1.0f);
+                        v3 dst = worldPoint - h.hitPoint;
+                        v3 dir = normalize(dst);
+                        generated++;
+                        float4 c = make_float4(0, 0, 0, 0);  // a direction below the surface is abandoned (RI:347-352)
+                        if (!(dot(h.normal, dir) < 0)) {
+                            float hitAngleDot = fmaxf_(dot(V3(tri.worldNormal), dir), 0);
+                            float BRDF = 1.0f;
+                            float weight = lightObject.brightness * BRDF * hitAngleDot / dot(dst, dst);  // RI:317-323
+                            c = make_float4(dir.x, dir.y, dir.z, weight);
+                        }
+                        stage[lane * RIS_STAGE_ROW + jj] = c;
                     }
-                    float hitAngleDot = fmaxf_(dot(V3(tri.worldNormal), dir), 0);
-                    float BRDF = 1.0f;
-                    float weight = lightObject.brightness * BRDF * hitAngleDot / dot(dst, dst);  // RI:317-323
-                    storeRisCandidate(P, candidateIndex, make_float4(dir.x, dir.y, dir.z, weight));
                 }
+                // the wave's lanes run in lockstep and the compiler orders LDS accesses with waitcnt: no barrier needed
+                // for data a wave exchanges with itself, only a fence against reordering
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                for (int r = 0; r < 64; r += 64 / RIS_STAGE) {
+                    const int row = r + (int)(lane / RIS_STAGE), piece = (int)(lane % RIS_STAGE);
+                    const int base = rowBase[row];
+                    if (base >= 0 && piece < nj) storeRisCandidate(P, base + piece, stage[row * RIS_STAGE_ROW + piece]);
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             }
         }
     }
@@ -306,7 +344,7 @@ __global__ __launch_bounds__(256) void k_ris_calc_tri_normals(rt_ris_tri* tris, 
     tris[i].worldNormal = {n.x, n.y, n.z};
 }
 
-// Baked triangles (see rt_device.h) from the RIS project's inline-vertex triangles; the fourth quad is unused.
+// Baked triangles (see rt_device.h) from the RIS project's inline-vertex triangles; the fourth quad holds the area.
 __global__ void k_ris_bake_tris(const rt_ris_tri* tris, int64_t nTris, float4* out) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= nTris) return;
@@ -317,7 +355,7 @@ __global__ void k_ris_bake_tris(const rt_ris_tri* tris, int64_t nTris, float4* o
     out[i * 4 + 0] = make_float4(v0.x, v0.y, v0.z, N.x);
     out[i * 4 + 1] = make_float4(eAB.x, eAB.y, eAB.z, N.y);
     out[i * 4 + 2] = make_float4(eAC.x, eAC.y, eAC.z, N.z);
-    out[i * 4 + 3] = make_float4(0, 0, 0, 0);
+    out[i * 4 + 3] = make_float4(length(N) * 0.5f, 0, 0, 0);  // GetTriArea, see risTriArea
 }
 
 }  // namespace rtn
