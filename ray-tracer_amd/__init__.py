@@ -24,4 +24,4 @@ from .bindings import (  # noqa: F401
     ris_default_config,
     world_to_local,
 )
-from .scenes import build_scene_s0, build_scene_instanced, ASSET_DIR  # noqa: F401
+from .scenes import build_scene_s0, build_scene_instanced, build_scene_textured, procedural_textures, ASSET_DIR  # noqa: F401

@@ -131,7 +131,15 @@ class _SceneData(C.Structure):
                 ("nSceneObjects", C.c_int64), ("LightObjects", C.c_void_p), ("nLightObjects", C.c_int64),
                 ("Materials", C.c_void_p), ("nMaterials", C.c_int64), ("ComponentDatas", C.c_void_p),
                 ("nComponentDatas", C.c_int64), ("maxBVHDepth", C.c_int32), ("emittingObjectsNum", C.c_int32),
-                ("sceneBVHStartIndex", C.c_int32), ("totArea", C.c_float)]
+                ("sceneBVHStartIndex", C.c_int32), ("totArea", C.c_float), ("atlas", C.c_void_p),
+                ("atlasWidth", C.c_int32), ("atlasHeight", C.c_int32)]
+
+
+class _TextureInput(C.Structure):
+    _fields_ = [("width", C.c_int32), ("height", C.c_int32), ("pixels", C.c_void_p)]
+
+
+TEXTURE_SLOTS = ("col", "bump", "roughness", "metallicity", "normals")   # RTH_TEX_* order
 
 
 class DispatchStats(C.Structure):
@@ -172,6 +180,7 @@ def host_lib():
             "rth_mesh_vertices": (vp, [vp]), "rth_mesh_triangles": (vp, [vp]),
             "rth_scene_create": (vp, [ci, ci]), "rth_scene_free": (None, [vp]),
             "rth_scene_add_material": (ci, [vp, C.POINTER(_MaterialInput)]), "rth_scene_add_mesh": (ci, [vp, vp]),
+            "rth_scene_add_material_textured": (ci, [vp, C.POINTER(_MaterialInput), C.POINTER(_TextureInput)]),
             "rth_scene_add_object": (ci, [vp, ci, fp, fp, fp, ci, ci]), "rth_scene_build": (ci, [vp, ci]),
             "rth_scene_get": (ci, [vp, C.POINTER(_SceneData)]), "rth_scene_save_json": (ci, [vp, cs]),
             "rth_scene_load_json": (ci, [vp, cs, cs, C.c_char_p, ci]), "rth_world_to_local": (None, [fp, fp, fp, fp, fp]),
@@ -277,9 +286,23 @@ class Scene:
             raise NativeError("scene creation failed")
         self._data = None
 
-    def add_material(self, brightness, col, roughness=0.0, metallicity=0.0, bump=0.0):
+    def add_material(self, brightness, col, roughness=0.0, metallicity=0.0, bump=0.0, textures=None):
+        """textures: optional {"col" | "bump" | "roughness" | "metallicity" | "normals": (H, W, 4) uint8 array}."""
         m = _MaterialInput(brightness, (C.c_float * 3)(*col), roughness, metallicity, bump)
-        return host_lib().rth_scene_add_material(self.h, C.byref(m))
+        if not textures:
+            return host_lib().rth_scene_add_material(self.h, C.byref(m))
+        tex = (_TextureInput * 5)()
+        keep = []
+        for k, slot in enumerate(TEXTURE_SLOTS):
+            if slot in textures:
+                a = np.ascontiguousarray(textures[slot], dtype=np.uint8)
+                assert a.ndim == 3 and a.shape[2] == 4, "textures are (H, W, 4) RGBA8 arrays"
+                keep.append(a)
+                tex[k] = _TextureInput(a.shape[1], a.shape[0], a.ctypes.data)
+        r = host_lib().rth_scene_add_material_textured(self.h, C.byref(m), tex)
+        if r < 0:
+            raise NativeError("rth_scene_add_material_textured failed")
+        return r
 
     def add_mesh(self, mesh):
         return host_lib().rth_scene_add_mesh(self.h, mesh.h)
@@ -333,6 +356,8 @@ class Scene:
             "ComponentDatas": self._arr(d.ComponentDatas, d.nComponentDatas, "Int2"),
             "maxBVHDepth": int(d.maxBVHDepth), "emittingObjectsNum": int(d.emittingObjectsNum),
             "sceneBVHStartIndex": int(d.sceneBVHStartIndex), "totArea": float(d.totArea),
+            "atlas": np.ctypeslib.as_array(C.cast(d.atlas, C.POINTER(C.c_uint8)),
+                                           (int(d.atlasHeight), int(d.atlasWidth), 4)).copy(),
         }
 
     def __del__(self):

@@ -126,9 +126,9 @@ struct rth_main_s {
         if (cfg.DoVisibilityReuse) rtShader.EnableKeyword("VIS_REUSE"); else rtShader.DisableKeyword("VIS_REUSE");
         if (cfg.DoWeightRecalc) rtShader.EnableKeyword("WEIGHT_RECALC"); else rtShader.DisableKeyword("WEIGHT_RECALC");
         if (cfg.DoBRDF) rtShader.EnableKeyword("BRDF"); else rtShader.DisableKeyword("BRDF");
-        // Object textures: the committed scene's materials carry no usable texture (its one normal map is not in the
-        // snapshot), so the atlas is a 1x1 black texel and the environment map a 1x1 sky colour.
-        int textureAtlasDims[2] = {1, 1};
+        // Object textures (Main.cs:259-267): the atlas ConstructTextureAtlas packed (1x1 black when no material has a
+        // texture); the environment map is a 1x1 sky colour (the reference's HDR map is not in the snapshot).
+        int textureAtlasDims[2] = {scene.atlasWidth, scene.atlasHeight};
         rtShader.SetInts("TextureAtlasDims", textureAtlasDims, 2);
         rtShader.SetTexture(0, "TextureAtlas", TextureAtlas);
         rtShader.SetTexture(4, "TextureAtlas", TextureAtlas);
@@ -143,7 +143,9 @@ struct rth_main_s {
         rtShader.SetInt("SceneBVHStartIndex", scene.sceneBVHStartIndex);
         rtShader.SetInt("EmittingObjectsNum", scene.emittingObjectsNum);
         if (!TextureAtlas.h) {
-            TextureAtlas = CreateTexture(ctx, {1, 1}, RT_FORMAT_RGBA8_UNORM);
+            TextureAtlas = CreateTexture(ctx, {scene.atlasWidth, scene.atlasHeight}, RT_FORMAT_RGBA8_UNORM);
+            int rca = rt_texture_set_data(TextureAtlas.h, scene.atlas, (size_t)scene.atlasWidth * scene.atlasHeight * 4);
+            if (rca < 0) throw DriverError{std::string("TextureAtlas upload: ") + rt_last_error(ctx)};
             EnvironmentMapTexture = CreateTexture(ctx, {1, 1}, RT_FORMAT_RGBA32F);
             const float sky[4] = {0.5f, 0.7f, 1.0f, 1.0f};
             int rc = rt_texture_set_data(EnvironmentMapTexture.h, sky, sizeof sky);

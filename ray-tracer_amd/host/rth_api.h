@@ -48,11 +48,27 @@ typedef struct {
     float bump;
 } rth_material_input;
 
+/* A texture of a MaterialInput: width x height RGBA8 texels, row 0 first (copied).  pixels == NULL: no texture. */
+typedef struct {
+    int32_t width, height;
+    const unsigned char* pixels;
+} rth_texture_input;
+enum { RTH_TEX_COL = 0, RTH_TEX_BUMP = 1, RTH_TEX_ROUGHNESS = 2, RTH_TEX_METALLICITY = 3, RTH_TEX_NORMALS = 4 };
+
 /* splitResolution, maxDepthSceneBVH: ObjectHelper.SplitResolution / MaxDepthSceneBVH (ObjectHelper.cs:19-20). */
 rth_scene rth_scene_create(int splitResolution, int maxDepthSceneBVH);
 void rth_scene_free(rth_scene s);
 /* Returns the material index. */
 int rth_scene_add_material(rth_scene s, const rth_material_input* m);
+/* The same with the material's five optional textures (indexed by RTH_TEX_*): ConstructTextureAtlas
+ * (ObjectHelper.cs:370-452) packs them into one RGBA8 atlas when the scene is built and the material then refers to
+ * its textures by location and size in the atlas (col / bump / roughness / metallicity = -1 select the texture).
+ * Unity's Texture2D.PackTextures is replaced by a deterministic shelf packer with the same 1-texel padding, so the
+ * locations differ from Unity's; the kernels only ever see locations.  As in the reference, metallicity textures are
+ * NOT added to the list that is packed although they consume a rectangle (:373-379 against :430-437): a material
+ * with one is given the rectangle of the texture that follows, the last texture of the scene finds none left, and
+ * rth_scene_build fails where the C# throws IndexOutOfRangeException. */
+int rth_scene_add_material_textured(rth_scene s, const rth_material_input* m, const rth_texture_input tex[5]);
 /* Registers a mesh (copied) and returns its mesh id.  Objects that share a mesh id share one BVH, which is
  * what the reference's mesh-key lookup does (ObjectHelper.cs:582-594). */
 int rth_scene_add_mesh(rth_scene s, rth_mesh m);
@@ -72,6 +88,7 @@ typedef struct {
     const rt_int2* ComponentDatas; int64_t nComponentDatas; /* (componentStart, totComponents) per BV node */
     int32_t maxBVHDepth, emittingObjectsNum, sceneBVHStartIndex;
     float totArea;
+    const unsigned char* atlas; int32_t atlasWidth, atlasHeight; /* RGBA8, row 0 first; 1x1 black without textures */
 } rth_scene_data;
 int rth_scene_get(rth_scene s, rth_scene_data* out);
 

@@ -17,6 +17,7 @@
 #include <cfloat>
 #include <cmath>
 #include <cstdio>
+#include <array>
 #include <cstring>
 #include <map>
 #include <string>
@@ -324,6 +325,10 @@ struct rth_scene_s {
     int splitResolution, maxDepthSceneBVH;
     std::vector<rth_mesh_s> meshes;
     std::vector<rth_material_input> materialInputs;
+    struct Tex { int w = 0, h = 0; std::vector<unsigned char> px; };
+    std::vector<std::array<Tex, 5>> materialTextures;  // per material, indexed by RTH_TEX_*
+    std::vector<unsigned char> atlas;
+    int atlasW = 1, atlasH = 1;
     std::vector<ObjectDesc> objects;
     // outputs
     std::vector<rt_bv> BVs;
@@ -351,6 +356,20 @@ void rth_scene_free(rth_scene s) { delete s; }
 int rth_scene_add_material(rth_scene s, const rth_material_input* m) {
     if (!s || !m) return -1;
     s->materialInputs.push_back(*m);
+    s->materialTextures.emplace_back();
+    return (int)s->materialInputs.size() - 1;
+}
+int rth_scene_add_material_textured(rth_scene s, const rth_material_input* m, const rth_texture_input tex[5]) {
+    if (!s || !m || !tex) return -1;
+    std::array<rth_scene_s::Tex, 5> t;
+    for (int k = 0; k < 5; k++) {
+        if (!tex[k].pixels) continue;
+        if (tex[k].width < 1 || tex[k].height < 1 || tex[k].width > 8192 || tex[k].height > 8192) return -1;
+        t[(size_t)k].w = tex[k].width; t[(size_t)k].h = tex[k].height;
+        t[(size_t)k].px.assign(tex[k].pixels, tex[k].pixels + (size_t)tex[k].width * tex[k].height * 4);
+    }
+    s->materialInputs.push_back(*m);
+    s->materialTextures.push_back(std::move(t));
     return (int)s->materialInputs.size() - 1;
 }
 int rth_scene_add_mesh(rth_scene s, rth_mesh m) {
@@ -388,7 +407,7 @@ int rth_scene_build(rth_scene s, int threads) {
     const int nObj = (int)s->objects.size();
     const int nMesh = (int)s->meshes.size();
 
-    rth_scene_make_materials(s);
+    if (!rth_scene_make_materials(s)) return -1;
 
     // ---- LoadSceneObjects (:556-607): meshes get their BVH the first time an object uses them ----
     std::vector<int> firstUseOrder;          // mesh ids in order of first use
@@ -539,20 +558,66 @@ SceneArraysRef rth_scene_arrays_ref(rth_scene s) {
                         &s->maxBVHDepth, &s->emittingObjectsNum, &s->sceneBVHStartIndex, &s->totArea, &s->built};
     return r;
 }
-// The scalar path of ConstructTextureAtlas (ObjectHelper.cs:390-449): one Material2 per registered material input.
-void rth_scene_make_materials(rth_scene s) {
+// ConstructTextureAtlas (ObjectHelper.cs:370-452): packs the materials' textures into one atlas and fills one Material2
+// per material input.  Returns false when a material refers to a rectangle that was never packed.
+bool rth_scene_make_materials(rth_scene s) {
+    // the list that is packed: col, bump, roughness, normals of every material, in that order (:373-379)
+    struct Item { const rth_scene_s::Tex* t; int x = 0, y = 0; };
+    std::vector<Item> items;
+    for (const auto& mt : s->materialTextures)
+        for (int k : {RTH_TEX_COL, RTH_TEX_BUMP, RTH_TEX_ROUGHNESS, RTH_TEX_NORMALS})
+            if (mt[(size_t)k].w) items.push_back({&mt[(size_t)k]});
+    s->atlasW = s->atlasH = 1;
+    s->atlas.assign(4, 0);
+    if (!items.empty()) {
+        // shelf packing with 1 texel of padding, into the smallest power-of-two square that takes everything
+        const int pad = 1;
+        for (int size = 2;; size *= 2) {
+            int x = 0, y = 0, shelf = 0;
+            bool fits = true;
+            for (auto& it : items) {
+                if (it.t->w + pad > size) { fits = false; break; }
+                if (x + it.t->w + pad > size) { x = 0; y += shelf; shelf = 0; }
+                if (y + it.t->h + pad > size) { fits = false; break; }
+                it.x = x; it.y = y;
+                x += it.t->w + pad;
+                if (it.t->h + pad > shelf) shelf = it.t->h + pad;
+            }
+            if (fits) { s->atlasW = s->atlasH = size; break; }
+            if (size >= 16384) return false;
+        }
+        s->atlas.assign((size_t)s->atlasW * s->atlasH * 4, 0);
+        for (const auto& it : items)
+            for (int r = 0; r < it.t->h; r++)
+                memcpy(&s->atlas[((size_t)(it.y + r) * s->atlasW + it.x) * 4], &it.t->px[(size_t)r * it.t->w * 4], (size_t)it.t->w * 4);
+    }
+    // Rect[] of PackTextures is normalised; GetTexLoc / GetTexDims scale back and truncate (:386-387)
+    auto loc = [&](const Item& it) { return rt_int2{(int)(((float)it.x / (float)s->atlasW) * (float)s->atlasW), (int)(((float)it.y / (float)s->atlasH) * (float)s->atlasH)}; };
+    auto dims = [&](const Item& it) { return rt_int2{(int)(((float)it.t->w / (float)s->atlasW) * (float)s->atlasW), (int)(((float)it.t->h / (float)s->atlasH) * (float)s->atlasH)}; };
+    size_t rectIndex = 0;
+    bool ok = true;
+    auto take = [&](rt_int2& outLoc, rt_int2& outDims) {
+        if (rectIndex >= items.size()) { ok = false; return; }
+        outLoc = loc(items[rectIndex]);
+        outDims = dims(items[rectIndex]);
+        rectIndex++;
+    };
     s->materials.clear();
-    for (const auto& mi : s->materialInputs) {
+    for (size_t i = 0; i < s->materialInputs.size(); i++) {
+        const auto& mi = s->materialInputs[i];
+        const auto& mt = s->materialTextures[i];
         rt_material m;
         memset(&m, 0, sizeof m);
         m.brightness = mi.brightness;
-        m.col = {mi.col[0], mi.col[1], mi.col[2]};
-        m.bump = mi.bump;
-        m.roughness = mi.roughness;
-        m.metallicity = mi.metallicity;
-        m.normalsTexLoc = {-1, -1};
+        if (mt[RTH_TEX_COL].w) { take(m.colTexLoc, m.colTexDims); m.col = {-1, -1, -1}; } else m.col = {mi.col[0], mi.col[1], mi.col[2]};
+        if (mt[RTH_TEX_BUMP].w) { take(m.bumpTexLoc, m.bumpTexDims); m.bump = -1; } else m.bump = mi.bump;
+        if (mt[RTH_TEX_ROUGHNESS].w) { take(m.roughnessTexLoc, m.roughnessTexDims); m.roughness = -1; } else m.roughness = mi.roughness;
+        // consumes a rectangle although metallicity textures were never packed (:430-437)
+        if (mt[RTH_TEX_METALLICITY].w) { take(m.metallicityTexLoc, m.metallicityTexDims); m.metallicity = -1; } else m.metallicity = mi.metallicity;
+        if (mt[RTH_TEX_NORMALS].w) take(m.normalsTexLoc, m.normalsTexDims); else m.normalsTexLoc = {-1, -1};
         s->materials.push_back(m);
     }
+    return ok;
 }
 
 extern "C" {
@@ -570,6 +635,7 @@ int rth_scene_get(rth_scene s, rth_scene_data* out) {
     out->emittingObjectsNum = s->emittingObjectsNum;
     out->sceneBVHStartIndex = s->sceneBVHStartIndex;
     out->totArea = s->totArea;
+    out->atlas = s->atlas.data(); out->atlasWidth = s->atlasW; out->atlasHeight = s->atlasH;
     return 0;
 }
 

@@ -318,7 +318,7 @@ int rth_scene_load_json(rth_scene s, const char* folder, const char* prefix, cha
         *a.BVs = BVs; *a.vertices = verts; *a.triangles = tris; *a.sceneObjects = objs; *a.lightObjects = lights; *a.componentDatas = comps;
         *a.maxBVHDepth = (int)keyed["maxBVHDepth"]; *a.emittingObjectsNum = (int)keyed["emittingObjectsNum"];
         *a.sceneBVHStartIndex = (int)keyed["sceneBVHStartIndex"]; *a.totArea = (float)keyed["totArea"];
-        rth_scene_make_materials(s);
+        if (!rth_scene_make_materials(s)) throw ParseError{"the scene's material textures cannot be packed"};
         *a.built = true;
     } catch (const ParseError& e) {
         return fail(std::string(key) + ".json: " + e.msg);

@@ -19,4 +19,4 @@ struct SceneArraysRef {
     bool* built;
 };
 SceneArraysRef rth_scene_arrays_ref(rth_scene s);
-void rth_scene_make_materials(rth_scene s);
+bool rth_scene_make_materials(rth_scene s);

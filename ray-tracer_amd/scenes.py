@@ -62,3 +62,44 @@ def build_scene_instanced(grid=(16, 8), emissive_objects=10, emissive_tris=1000,
         s.add_object(md, (-4 + 9.0 * gx * (e / max(1, emissive_objects - 1) - 0.5), 12.0, 13 + 4.5 * gy), (90, 0, 0),
                      (6, 6, 6), 2, 12)
     return s.build(threads)
+
+
+def procedural_textures(seed=7):
+    """Small RGBA8 textures for the textured-material tests: a colour checker, a bump map, a roughness map and a
+    normal map (tangent-space style: mostly +z)."""
+    import numpy as np
+    rng = np.random.default_rng(seed)
+    yy, xx = np.mgrid[0:32, 0:32]
+    col = np.zeros((32, 32, 4), np.uint8)
+    col[..., 0] = 40 + 200 * ((xx // 4 + yy // 4) % 2)
+    col[..., 1] = (xx * 8) % 256
+    col[..., 2] = (yy * 8) % 256
+    col[..., 3] = 255
+    bump = np.zeros((8, 4, 4), np.uint8)
+    bump[..., 0] = rng.integers(0, 4, (8, 4))          # bump offsets of up to 3/255 along the incoming direction
+    rough = np.zeros((8, 8, 4), np.uint8)
+    rough[..., 0] = rng.integers(30, 255, (8, 8))
+    normals = np.zeros((16, 16, 4), np.uint8)
+    normals[..., 0] = 128 + rng.integers(-40, 40, (16, 16))
+    normals[..., 1] = 128 + rng.integers(-40, 40, (16, 16))
+    normals[..., 2] = 255
+    return {"col": col, "bump": bump, "roughness": rough, "normals": normals}
+
+
+def build_scene_textured(threads=0):
+    """Scene S0 (8.7k dragon) whose dragon material takes colour, bump, roughness and normals from textures and whose
+    light is tinted by a colour texture: every atlas-sampling path of the kernels except the metallicity texture
+    (which the reference's atlas builder cannot produce, ObjectHelper.cs:373-379,430-437)."""
+    dragon = Mesh.load(os.path.join(ASSET_DIR, "dragon8k.rtmesh"))
+    suzanne = Mesh.load(os.path.join(ASSET_DIR, "suzanne.rtmesh"))
+    tex = procedural_textures()
+    s = Scene(split_resolution=5, max_depth_scene_bvh=10)
+    s.add_material(0.0, (1, 1, 0), roughness=0.0, metallicity=0.0)
+    s.add_material(0.0, (0, 1, 0), roughness=0.8, metallicity=1.0, textures=tex)
+    light = tex["col"].copy()
+    light[..., :3] = 255 - light[..., :3] // 4
+    s.add_material(40000.0, (1, 1, 1), roughness=1.0, metallicity=1.0, textures={"col": light[:16, :24]})
+    md, ms = s.add_mesh(dragon), s.add_mesh(suzanne)
+    s.add_object(ms, (0.5, 4.4, 14.6), (0, 190, 0), (2, 2, 2), 2, 14)
+    s.add_object(md, (-4, -2, 13), (0, 0, 0), (12, 12, 12), 1, 18)
+    return s.build(threads)

@@ -116,7 +116,9 @@ class OracleRenderer:
                                                                   "NormalsBuffer", "RayHitPointsA", "RayHitPointsB")}
         self.tex["DepthBuffer"] = np.zeros((H, W), np.float32)
         self.records = np.zeros(n, DT["TraceRecord"]) if records else None
-        self.atlas = np.zeros((1, 1, 4), np.float32)
+        # the RGBA8 atlas as the library converts it on upload: texel / 255 in fp32
+        self.atlas = np.ascontiguousarray(self.a["atlas"].astype(np.float32) / np.float32(255.0)) if "atlas" in self.a \
+            else np.zeros((1, 1, 4), np.float32)
         self.env = np.array([[[0.5, 0.7, 1.0, 1.0]]], np.float32)
         self.counters = OrcCounters()
         self.FrameCount = 0
@@ -131,7 +133,7 @@ class OracleRenderer:
         s.Materials, s.nMaterials = a["Materials"].ctypes.data, len(a["Materials"])
         s.Triangles, s.nTriangles = a["Triangles"].ctypes.data, len(a["Triangles"])
         s.Vertices, s.nVertices = a["Vertices"].ctypes.data, len(a["Vertices"])
-        s.TextureAtlas, s.atlasW, s.atlasH = self.atlas.ctypes.data, 1, 1
+        s.TextureAtlas, s.atlasW, s.atlasH = self.atlas.ctypes.data, self.atlas.shape[1], self.atlas.shape[0]
         s.EnvironmentMap, s.envW, s.envH = self.env.ctypes.data, 1, 1
         self.s = s
         f = OrcFrame()
@@ -174,7 +176,7 @@ class OracleRenderer:
         p.SpatialBRDFThreshold = cfg.SpatialBRDFThreshold
         p.TemporalReuseWeight, p.PixelMovementThreshold = cfg.TemporalReuseWeight, cfg.PixelMovementThreshold
         p.TemporalPrecisionThreshold = cfg.TemporalPrecisionThreshold
-        p.TextureAtlasDimsRaw[0] = p.TextureAtlasDimsRaw[1] = 1      # SetInts("TextureAtlasDims", {1, 1})
+        p.TextureAtlasDimsRaw[0], p.TextureAtlasDimsRaw[1] = self.atlas.shape[1], self.atlas.shape[0]  # SetInts("TextureAtlasDims")
         p.EnvironmentMapTexDimsRaw[0] = p.EnvironmentMapTexDimsRaw[1] = 1
         p.kw_VIS_REUSE, p.kw_WEIGHT_RECALC, p.kw_BRDF = cfg.DoVisibilityReuse, cfg.DoWeightRecalc, cfg.DoBRDF
         p.row0, p.row1 = row0, row1
