@@ -103,6 +103,8 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if "RT_BENCH_DEVICE" in os.environ:   # rehearsals on a box with fewer GPUs than ranks
+        local_rank = int(os.environ["RT_BENCH_DEVICE"])
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             sys.exit("bench.py --gpus N > 1 must be launched with torch.distributed.run (one process per GPU)")

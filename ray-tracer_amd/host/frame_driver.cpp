@@ -494,8 +494,10 @@ rth_mg rth_mg_create(rth_main m, int rank, int world, const int* bounds, const u
     const int total = rth_mg_halo_plan(m->cfg.SpatialReuseIterations, m->cfg.SpatialReuseBlur, nullptr, nullptr);
     for (int r = 0; r < world; r++)
         if (world > 1 && g->bounds[(size_t)r + 1] - g->bounds[(size_t)r] < total) { delete g; return fail("a band is shorter than the halo: use fewer GPUs or a larger image"); }
-    if (world > 1 || uniqueId) {  // a communicator of one rank is legal (and lets a single GPU exercise the set-up)
-        if (!uniqueId) { delete g; return fail("a unique id is needed for more than one rank"); }
+    // A communicator of one rank is legal (and lets a single GPU exercise the set-up).  Several ranks WITHOUT an id
+    // get no communicator: such a rank can only be stepped with rth_mg_phase / rth_mg_plan, by a test that carries
+    // the transfers out itself.
+    if (uniqueId) {
         if (!rccl().ok) { std::string w = rccl().why; delete g; return fail(w); }
         Rccl::UniqueId id;
         memcpy(id.internal, uniqueId, 128);
@@ -543,80 +545,132 @@ int rth_mg_loopback(rth_mg g, int src0, int src1, int dst0) {
     return 0;
 }
 
+}  // extern "C"
+
+namespace {
+
+void mgCheck(rth_mg g, int rc, const char* what) {
+    if (rc < 0) throw DriverError{std::string(what) + ": " + rt_last_error(g->m->ctx)};
+}
+// Appends the transfers of rows [r0, r1) of a reservoir buffer and/or a texture to or from `peer`.
+void mgRows(rth_mg g, std::vector<rth_xfer>& plan, bool send, rt_buffer buf, rt_texture tex, int r0, int r1, int peer) {
+    if (r1 <= r0) return;
+    rt_segment seg[5];
+    int cnt = 0;
+    if (buf) mgCheck(g, rt_buffer_map_rows(buf, g->m->cfg.Resolution[0], r0, r1, seg, &cnt), "rt_buffer_map_rows");
+    if (tex) { mgCheck(g, rt_texture_map_rows(tex, r0, r1, &seg[cnt]), "rt_texture_map_rows"); cnt++; }
+    for (int k = 0; k < cnt; k++) plan.push_back({send ? 1 : 0, peer, seg[k].ptr, seg[k].bytes});
+}
+// The one halo exchange of a frame: my border rows of the first spatial pass's source buffer and of the depth buffer go
+// to both neighbours, theirs come here, `total` rows deep.
+void mgPlanHalo(rth_mg g, std::vector<rth_xfer>& plan) {
+    rth_main m = g->m;
+    const int rank = g->rank, world = g->world, H = m->cfg.Resolution[1];
+    const int b0 = g->bounds[(size_t)rank], b1 = g->bounds[(size_t)rank + 1];
+    const int total = rth_mg_halo_plan(m->cfg.SpatialReuseIterations, m->cfg.SpatialReuseBlur, nullptr, nullptr);
+    if (m->cfg.SpatialReuseIterations <= 0) return;
+    rt_buffer cand = m->CandidateBuffer.h;
+    rt_texture depth = m->DepthBufferTexture.h;
+    if (rank > 0) {
+        mgRows(g, plan, true, cand, depth, b0, b0 + total < b1 ? b0 + total : b1, rank - 1);
+        mgRows(g, plan, false, cand, depth, b0 - total > 0 ? b0 - total : 0, b0, rank - 1);
+    }
+    if (rank < world - 1) {
+        mgRows(g, plan, true, cand, depth, b1 - total > b0 ? b1 - total : b0, b1, rank + 1);
+        mgRows(g, plan, false, cand, depth, b1, b1 + total < H ? b1 + total : H, rank + 1);
+    }
+}
+// The displayed image is completed on rank 0.
+void mgPlanGather(rth_mg g, std::vector<rth_xfer>& plan) {
+    rth_main m = g->m;
+    if (g->rank == 0) {
+        for (int r = 1; r < g->world; r++) mgRows(g, plan, false, nullptr, m->RTResultTexture.h, g->bounds[(size_t)r], g->bounds[(size_t)r + 1], r);
+    } else {
+        mgRows(g, plan, true, nullptr, m->RTResultTexture.h, g->bounds[(size_t)g->rank], g->bounds[(size_t)g->rank + 1], 0);
+    }
+}
+// Phase 0 of a frame: everything before the halo exchange.  Phase 1: everything after it.
+void mgPhase(rth_mg g, int phase) {
+    rth_main m = g->m;
+    rt_ctx ctx = m->ctx;
+    const int rank = g->rank, world = g->world, H = m->cfg.Resolution[1];
+    const int b0 = g->bounds[(size_t)rank], b1 = g->bounds[(size_t)rank + 1];
+    auto rows = [&](int r0, int r1) { mgCheck(g, rt_set_row_band(ctx, r0, r1), "rt_set_row_band"); };
+    m->CreateTextures();
+    if (phase == 0) {
+        rows(b0, b1);
+        m->UpdatePerFrame();
+        m->RunStage(0);
+        m->RunStage(1);
+        return;
+    }
+    const int iterations = m->cfg.SpatialReuseIterations;
+    if (iterations > 0) {
+        std::vector<int> halo((size_t)iterations), extend((size_t)iterations);
+        rth_mg_halo_plan(iterations, m->cfg.SpatialReuseBlur, halo.data(), extend.data());
+        for (int i = 0; i < iterations; i++) {
+            // the earlier passes also write the rows the later passes will read from beyond the band
+            int lo = rank > 0 ? b0 - extend[(size_t)i] : b0, hi = rank < world - 1 ? b1 + extend[(size_t)i] : b1;
+            rows(lo > 0 ? lo : 0, hi < H ? hi : H);
+            m->SpatialReusePass(i);
+        }
+        rows(b0, b1);
+        m->TransferIfNeeded();
+    }
+    m->RunStage(3);
+    m->RunPostProcessingShader();
+}
+void mgRun(rth_mg g, const std::vector<rth_xfer>& plan) {
+    if (plan.empty()) return;
+    auto nccl = [&](int rc, const char* what) { if (rc != 0) throw DriverError{std::string(what) + ": " + rccl().GetErrorString(rc)}; };
+    void* stream = rt_stream(g->m->ctx);
+    nccl(rccl().GroupStart(), "ncclGroupStart");
+    for (const auto& x : plan) {
+        if (x.send) nccl(rccl().Send(x.ptr, x.bytes, NCCL_UINT8, x.peer, g->comm, stream), "ncclSend");
+        else nccl(rccl().Recv(x.ptr, x.bytes, NCCL_UINT8, x.peer, g->comm, stream), "ncclRecv");
+    }
+    nccl(rccl().GroupEnd(), "ncclGroupEnd");
+}
+
+}  // namespace
+
+extern "C" {
+
 // n banded frames, enqueued on the context's stream (asynchronous; rt_sync waits for them).
 int rth_mg_render_frames(rth_mg g, int n) {
     if (!g) return -1;
-    rth_main m = g->m;
-    rt_ctx ctx = m->ctx;
-    void* stream = rt_stream(ctx);
-    const int rank = g->rank, world = g->world, H = m->cfg.Resolution[1], W = m->cfg.Resolution[0];
-    const int b0 = g->bounds[(size_t)rank], b1 = g->bounds[(size_t)rank + 1];
-    const int iterations = m->cfg.SpatialReuseIterations;
-    std::vector<int> halo((size_t)(iterations > 0 ? iterations : 1)), extend(halo.size());
-    const int total = rth_mg_halo_plan(iterations, m->cfg.SpatialReuseBlur, halo.data(), extend.data());
+    if (g->world > 1 && !g->comm) { g->err = "this rank was created without a communicator"; return -1; }
     try {
-        auto check = [&](int rc, const char* what) { if (rc < 0) throw DriverError{std::string(what) + ": " + rt_last_error(ctx)}; };
-        auto nccl = [&](int rc, const char* what) { if (rc != 0) throw DriverError{std::string(what) + ": " + rccl().GetErrorString(rc)}; };
-        auto rows = [&](int r0, int r1) { check(rt_set_row_band(ctx, r0, r1), "rt_set_row_band"); };
-        // sends (or receives) rows [r0, r1) of the reservoir buffer `buf` and of the depth texture to (from) `peer`
-        auto moveRows = [&](bool send, rt_buffer buf, rt_texture tex, int r0, int r1, int peer) {
-            if (r1 <= r0) return;
-            rt_segment seg[5];
-            int cnt = 0;
-            if (buf) check(rt_buffer_map_rows(buf, W, r0, r1, seg, &cnt), "rt_buffer_map_rows");
-            if (tex) { check(rt_texture_map_rows(tex, r0, r1, &seg[cnt]), "rt_texture_map_rows"); cnt++; }
-            for (int k = 0; k < cnt; k++) {
-                if (send) nccl(rccl().Send(seg[k].ptr, seg[k].bytes, NCCL_UINT8, peer, g->comm, stream), "ncclSend");
-                else nccl(rccl().Recv(seg[k].ptr, seg[k].bytes, NCCL_UINT8, peer, g->comm, stream), "ncclRecv");
-            }
-        };
-        m->CreateTextures();
+        std::vector<rth_xfer> plan;
         for (int f = 0; f < n; f++) {
-            rows(b0, b1);
-            m->UpdatePerFrame();
-            m->RunStage(0);
-            m->RunStage(1);
-            if (iterations > 0) {
-                if (world > 1) {
-                    // one exchange per frame: my border rows of the first pass's source buffer and of the depth buffer
-                    // go to both neighbours, theirs come here, `total` rows deep
-                    nccl(rccl().GroupStart(), "ncclGroupStart");
-                    if (rank > 0) {
-                        moveRows(true, m->CandidateBuffer.h, m->DepthBufferTexture.h, b0, b0 + total < b1 ? b0 + total : b1, rank - 1);
-                        moveRows(false, m->CandidateBuffer.h, m->DepthBufferTexture.h, b0 - total > 0 ? b0 - total : 0, b0, rank - 1);
-                    }
-                    if (rank < world - 1) {
-                        moveRows(true, m->CandidateBuffer.h, m->DepthBufferTexture.h, b1 - total > b0 ? b1 - total : b0, b1, rank + 1);
-                        moveRows(false, m->CandidateBuffer.h, m->DepthBufferTexture.h, b1, b1 + total < H ? b1 + total : H, rank + 1);
-                    }
-                    nccl(rccl().GroupEnd(), "ncclGroupEnd");
-                }
-                for (int i = 0; i < iterations; i++) {
-                    // the earlier passes also write the rows the later passes will read from beyond the band
-                    int lo = rank > 0 ? b0 - extend[(size_t)i] : b0, hi = rank < world - 1 ? b1 + extend[(size_t)i] : b1;
-                    rows(lo > 0 ? lo : 0, hi < H ? hi : H);
-                    m->SpatialReusePass(i);
-                }
-                rows(b0, b1);
-                m->TransferIfNeeded();
-            }
-            m->RunStage(3);
-            m->RunPostProcessingShader();
-            if (world > 1) {  // the displayed image is completed on rank 0
-                nccl(rccl().GroupStart(), "ncclGroupStart");
-                if (rank == 0) {
-                    for (int r = 1; r < world; r++) moveRows(false, nullptr, m->RTResultTexture.h, g->bounds[(size_t)r], g->bounds[(size_t)r + 1], r);
-                } else {
-                    moveRows(true, nullptr, m->RTResultTexture.h, b0, b1, 0);
-                }
-                nccl(rccl().GroupEnd(), "ncclGroupEnd");
-            }
+            mgPhase(g, 0);
+            if (g->world > 1) { plan.clear(); mgPlanHalo(g, plan); mgRun(g, plan); }
+            mgPhase(g, 1);
+            if (g->world > 1) { plan.clear(); mgPlanGather(g, plan); mgRun(g, plan); }
         }
     } catch (const DriverError& e) {
         g->err = e.msg;
         return -1;
     }
     return 0;
+}
+// The two halves of a frame and the transfer lists between them, one at a time: lets a test that holds several ranks
+// in one process (all on one GPU, no communicator) carry the transfers out itself and so check the schedule.
+int rth_mg_phase(rth_mg g, int phase) {
+    if (!g || phase < 0 || phase > 1) return -1;
+    try { mgPhase(g, phase); } catch (const DriverError& e) { g->err = e.msg; return -1; }
+    return 0;
+}
+int rth_mg_plan(rth_mg g, int which, rth_xfer* out, int cap) {
+    if (!g || which < 0 || which > 1) return -1;
+    std::vector<rth_xfer> plan;
+    try {
+        g->m->CreateTextures();
+        if (which == 0) mgPlanHalo(g, plan); else mgPlanGather(g, plan);
+    } catch (const DriverError& e) { g->err = e.msg; return -1; }
+    if ((int)plan.size() > cap || (!out && !plan.empty())) return -1;
+    for (size_t i = 0; i < plan.size(); i++) out[i] = plan[i];
+    return (int)plan.size();
 }
 
 }  // extern "C"

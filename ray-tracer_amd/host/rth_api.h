@@ -177,7 +177,8 @@ int rth_mg_halo_plan(int iterations, int blur, int* halo, int* extend);
 /* ncclGetUniqueId on the calling rank; the 128 bytes must reach every rank (any side channel) before rth_mg_create. */
 int rth_mg_unique_id(unsigned char out[128]);
 /* bounds: band boundaries b[0..world] every rank agrees on, or NULL for rth_mg_band_bounds' equal heights.
- * Collective over all ranks (ncclCommInitRank) when world > 1; world == 1 needs no id and no RCCL.  `m` must have
+ * Collective over all ranks (ncclCommInitRank) when an id is given; without one no communicator is made (fine for
+ * world == 1; for world > 1 the rank can then only be stepped with rth_mg_phase / rth_mg_plan).  `m` must have
  * been created on a context of this rank's GPU with full-frame buffers (row0 = row1 = 0). */
 rth_mg rth_mg_create(rth_main m, int rank, int world, const int* bounds, const unsigned char uniqueId[128], char* err, int errLen);
 void rth_mg_destroy(rth_mg g);
@@ -186,6 +187,14 @@ int rth_mg_bounds(rth_mg g, int* out);
 /* Self-test: moves rows [src0, src1) of Candidates and DepthBuffer to row dst0 through RCCL send/recv addressed to
  * this same rank (needs a communicator, i.e. a unique id at creation). */
 int rth_mg_loopback(rth_mg g, int src0, int src1, int dst0);
+/* One transfer of a frame's exchange: bytes at ptr (device memory of this rank) sent to, or received from, peer. */
+typedef struct { int32_t send; int32_t peer; void* ptr; size_t bytes; } rth_xfer;
+/* A frame in steps, for tests that hold several ranks in one process and move the data themselves: phase 0 = the
+ * dispatches before the halo exchange, phase 1 = those after it; plan 0 = the halo exchange, plan 1 = the gather of
+ * the displayed image, as the lists of transfers rth_mg_render_frames would hand to RCCL, in order.  rth_mg_plan
+ * returns the number of entries, or -1. */
+int rth_mg_phase(rth_mg g, int phase);
+int rth_mg_plan(rth_mg g, int which, rth_xfer* out, int cap);
 /* Enqueues n banded frames (asynchronous).  After rt_sync, rank 0's Result texture holds the whole image. */
 int rth_mg_render_frames(rth_mg g, int n);
 

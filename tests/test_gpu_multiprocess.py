@@ -94,3 +94,95 @@ def test_native_frame_loop_single_rank(gpu_ctx, scene_small):
         assert np.isfinite(depth[40:52]).any()
     finally:
         runner.close()
+
+
+@pytest.mark.parametrize("world,res,balanced", [(2, (128, 96), False), (3, (96, 160), True), (8, (64, 384), False)])
+def test_native_schedule_many_ranks_in_process(scene_small, world, res, balanced):
+    """The C++ banded schedule for 2, 3 and 8 ranks, all held in this process on the one GPU: each rank is stepped
+    through the two halves of a frame (rth_mg_phase) and the transfer lists the frame loop would hand to RCCL
+    (rth_mg_plan) are carried out here with device-to-device copies, the k-th send of rank a to rank b matched with
+    the k-th receive of rank b from rank a, as RCCL matches them.  Rank 0's gathered image and every rank's band
+    must equal the single-GPU render bit for bit over several frames."""
+    import ctypes as C
+    import harness as h
+    rt = h.rt
+    bindings = importlib.import_module("ray-tracer_amd.bindings")
+    mg = importlib.import_module("ray-tracer_amd.multigpu")
+    hip = C.CDLL("libamdhip64.so")
+    hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    hip.hipMemcpy.restype = C.c_int
+    W, H = res
+    cfg = h.small_config(W, H)
+    host = rt.host_lib()
+    bounds = None
+    if balanced:  # uneven cuts, as the cost balancer would produce
+        bounds = [0, 48, 104, H]
+    ctxs = [rt.RtContext(0) for _ in range(world + 1)]
+    drvs = [rt.Driver(c, cfg, scene_small) for c in ctxs]
+    ref_ctx, ref = ctxs[world], drvs[world]
+    ranks = []
+    err = C.create_string_buffer(512)
+    try:
+        for r in range(world):
+            cb = (C.c_int * (world + 1))(*bounds) if bounds else None
+            g = host.rth_mg_create(drvs[r].h, r, world, cb, None, err, 512)
+            assert g, err.value.decode()
+            ranks.append(g)
+        b = (C.c_int * (world + 1))()
+        host.rth_mg_bounds(ranks[0], b)
+        cuts = list(b)
+        # a rank without a communicator cannot run the RCCL loop
+        assert host.rth_mg_render_frames(ranks[0], 1) != 0
+
+        def exchange(which):
+            plans = []
+            for g in ranks:
+                buf = (bindings.Xfer * 64)()
+                n = host.rth_mg_plan(g, which, buf, 64)
+                assert n >= 0, host.rth_mg_last_error(g)
+                plans.append([buf[i] for i in range(n)])
+            for c in ctxs[:world]:
+                c.sync()
+            moved = 0
+            for a in range(world):
+                for bb in range(world):
+                    sends = [x for x in plans[a] if x.send and x.peer == bb]
+                    recvs = [x for x in plans[bb] if not x.send and x.peer == a]
+                    assert len(sends) == len(recvs), (which, a, bb)
+                    for s, d in zip(sends, recvs):
+                        assert s.bytes == d.bytes and s.bytes > 0
+                        assert hip.hipMemcpy(d.ptr, s.ptr, s.bytes, 3) == 0
+                        moved += s.bytes
+            return moved
+
+        for frame in range(3):
+            for g in ranks:
+                assert host.rth_mg_phase(g, 0) == 0, host.rth_mg_last_error(g)
+            halo_bytes = exchange(0)
+            for g in ranks:
+                assert host.rth_mg_phase(g, 1) == 0, host.rth_mg_last_error(g)
+            gather_bytes = exchange(1)
+            for c in ctxs[:world]:
+                c.sync()
+            ref.render_frame()
+            ref_ctx.sync()
+            want = ref.texture("Result")
+            assert np.array_equal(h.bits(drvs[0].texture("Result")), h.bits(want)), frame
+            for r in range(world):
+                lo, hi = cuts[r], cuts[r + 1]
+                for name in ("Result", "AccumulatedResult", "DepthBuffer"):
+                    assert np.array_equal(h.bits(drvs[r].texture(name)[lo:hi]), h.bits(ref.texture(name)[lo:hi])), (frame, r, name)
+                for name in ("Candidates", "TemporalFrameBuffer", "HitInfos"):
+                    assert np.array_equal(h.bits(drvs[r].buffer(name)[lo * W:hi * W]), h.bits(ref.buffer(name)[lo * W:hi * W])), (frame, r, name)
+            # volume: every interior cut carries `total` rows each way of the reservoir planes and a 4-byte depth
+            _, _, total = mg.native_halo_plan(cfg.SpatialReuseIterations, cfg.SpatialReuseBlur)
+            per_pixel, rest = divmod(halo_bytes, 2 * (world - 1) * total * W)
+            assert rest == 0 and 52 + 4 <= per_pixel <= 64 + 4, halo_bytes
+            assert gather_bytes == (H - cuts[1]) * W * 16
+    finally:
+        for g in ranks:
+            host.rth_mg_destroy(g)
+        for d in drvs:
+            d.close()
+        for c in ctxs:
+            c.close()
