@@ -23,6 +23,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak
+RIS_TOT = RIS_TESTS = 32  # --project ris: candidates stored per pixel, candidates drawn per pixel in TraceRays
 
 
 def algorithmic_bytes(kernel, c, npx_launch):
@@ -32,8 +33,23 @@ def algorithmic_bytes(kernel, c, npx_launch):
     leaf-loop triangle, 60 B (three vertices) per triangle tested — the reference's access pattern — plus the
     per-pixel records the kernel streams.  Reuse passes: their per-pixel record traffic.
     """
-    trav = 32 * (c["pops"] + c["bvChecks"]) + 168 * c["objVisits"] + 28 * c["triIters"] + 60 * c["triChecks"]
+    c = {k: c.get(k, 0) for k in ("pops", "bvChecks", "objVisits", "triIters", "triChecks", "activePixels", "rays",
+                                   "validNeighbours")}
     px = c["activePixels"]
+    if kernel.startswith("ris_"):
+        # RIS project: 76-byte triangles with inline vertices (one fetch per leaf-loop iteration), 40-byte HitInfo,
+        # 16-byte candidates, RIS_TOT of them per pixel
+        trav = 32 * (c["pops"] + c["bvChecks"]) + 168 * c["objVisits"] + 76 * c["triIters"]
+        if kernel == "ris_primary":
+            return trav + npx_launch * (40 + 16 + 16)       # HitInfo, DebugOverlay, RayHitPoints written
+        if kernel == "ris_candidates":
+            # the kernel counts the candidates it generated (RIS_TOT per hit pixel): 16 B written each, plus the
+            # pixel's HitInfo read
+            return c["validNeighbours"] * 16 + c["validNeighbours"] / RIS_TOT * 40
+        if kernel == "ris_trace_rays":
+            return trav + npx_launch * (40 + 16) + px * 16 * RIS_TESTS   # HitInfo, Result; candidates drawn
+        return 0
+    trav = 32 * (c["pops"] + c["bvChecks"]) + 168 * c["objVisits"] + 28 * c["triIters"] + 60 * c["triChecks"]
     if kernel == "primary":
         return trav + px * (52 + 16 + 4 + 16 + 16)          # HitInfo, DebugOverlay, depth, normals, hit point
     if kernel == "candidates":
@@ -68,7 +84,8 @@ def cpu_baseline(rt, scene, cfg, frames, threads):
     """The CPU oracle (a port of the reference's kernels) on the same scene, resolution and constants."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import harness as h
-    orc = h.OracleRenderer(scene.arrays(), cfg, threads=threads, records=False)
+    ris = isinstance(cfg, rt.RisConfig)
+    orc = (h.RisOracleRenderer if ris else h.OracleRenderer)(scene.arrays(), cfg, threads=threads, records=False)
     orc.render_frame()  # frame 0 (no temporal history yet): untimed warm-up
     orc.take_counters()
     t0 = time.perf_counter()
@@ -77,7 +94,8 @@ def cpu_baseline(rt, scene, cfg, frames, threads):
     dt = time.perf_counter() - t0
     c = orc.take_counters()
     return {"value": c["rays"] / 1e6 / dt, "unit": "Mrays/s", "cores": threads, "kind": "port",
-            "sample": f"{frames} full ReSTIR frame(s) (frame index 1..{frames}) of the same 1920x1080 workload, "
+            "sample": f"{frames} full {'RIS' if ris else 'ReSTIR'} frame(s) (frame index 1..{frames}) of the same "
+                      f"{cfg.Resolution[0]}x{cfg.Resolution[1]} workload, "
                       f"{dt / frames * 1e3:.0f} ms/frame on {threads} threads",
             "ms_per_frame": dt / frames * 1e3}
 
@@ -92,9 +110,14 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-frames", type=int, default=2)
     ap.add_argument("--small-scene", action="store_true", help="8.7k-triangle dragon instead of the 78k stand-in")
-    ap.add_argument("--scene", choices=("80k", "instanced"), default="80k",
+    ap.add_argument("--scene", choices=("80k", "instanced", "unique"), default="80k",
                     help="instanced: 16x8 instances of the 78k dragon (10 M triangles through one shared mesh BVH) lit by "
-                         "10 discs of 1000 emissive triangles: the deep-BVH configuration")
+                         "10 discs of 1000 emissive triangles: the deep-BVH configuration.  unique: the same grid with "
+                         "every dragon a distinct (vertex-jittered) mesh with its own BVH: 10 M stored triangles, "
+                         "about 1.4 GB of nodes, triangles and vertices")
+    ap.add_argument("--project", choices=("restir", "ris"), default="restir",
+                    help="ris: the RIS project's frame (GenerateCandidates with 32 candidates per pixel, TraceRays "
+                         "drawing 32 of them, AccumulateFrames) instead of the ReSTIR sequence")
     ap.add_argument("--exchange", choices=("rccl", "torch"), default="rccl",
                     help="N > 1: halo exchange from the C++ frame loop with RCCL calls (default), or from Python with "
                          "torch.distributed's NCCL backend")
@@ -111,12 +134,18 @@ def main():
         args.gpus = world
 
     rt = importlib.import_module("ray-tracer_amd")
-    if args.scene == "instanced":
-        scene = rt.build_scene_instanced(grid=(16, 8), emissive_objects=10, emissive_tris=1000, unique=False,
-                                         subdivide=not args.small_scene)
+    if args.scene != "80k":
+        scene = rt.build_scene_instanced(grid=(16, 8), emissive_objects=10, emissive_tris=1000,
+                                         unique=args.scene == "unique", subdivide=not args.small_scene)
     else:
         scene = rt.build_scene_s0(subdivide=not args.small_scene)
-    cfg = rt.default_config()
+    ris = args.project == "ris"
+    if ris:
+        cfg = rt.ris_default_config()
+        cfg.TriCandidatesNum, cfg.CandidateReservoirTestsNum = RIS_TOT, RIS_TESTS
+        args.exchange = "rccl"        # its banded loop exists in the native driver only
+    else:
+        cfg = rt.default_config()
     cfg.Resolution[0], cfg.Resolution[1] = args.width, args.height
     W, H = args.width, args.height
 
@@ -159,6 +188,7 @@ def main():
     ctx.enable_stats(0)
 
     if rank == 0:
+        proj = "BVH_RIS_DL" if ris else "BVH_ReSTIR_DL"
         band_px = runner.band_pixels()
         kernels = {}
         for name, p in prof.items():
@@ -178,17 +208,19 @@ def main():
             d = timed[dominant]
             roofline = {"bound": "hbm", "kernel": dominant, "achieved": d["achieved_GBs"], "peak": HBM_PEAK_GBS,
                         "unit": "GB/s", "frac": d["achieved_GBs"] / HBM_PEAK_GBS,
-                        "traffic": pmc_traffic(dominant, W, H, world, args.small_scene, args.scene),
+                        "traffic": None if ris else pmc_traffic(dominant, W, H, world, args.small_scene, args.scene),
                         "avg_launch_ms": d["avg_ms"], "algorithmic_MB_per_launch": d["algorithmic_MB_per_launch"]}
         out = {
-            "metric": "Mrays/s (primary+shadow) ReSTIR DL, 80kScene 1080p",
+            "metric": "Mrays/s (primary+shadow) " + ("RIS DL" if ris else "ReSTIR DL") + ", 80kScene 1080p",
             "value": rays_total / 1e6 / dt_max, "unit": "Mrays/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": dt_max / args.steps * 1e3, "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": (f"BVH_ReSTIR_DL 80kScene* ({'8.7k' if args.small_scene else '78k'}-triangle dragon stand-in "
+            "config": {"workload": (f"{proj} 80kScene* ({'8.7k' if args.small_scene else '78k'}-triangle dragon stand-in "
                                     f"+ Suzanne light)" if args.scene == "80k" else
-                                    "BVH_ReSTIR_DL instanced 80kScene* (128 dragon instances + 10 emissive discs)") +
-                                   f" {W}x{H}, temporal + 3 spatial reuse passes, VIS_REUSE+BRDF",
+                                    f"{proj} {args.scene} 80kScene* (128 dragon "
+                                    f"{'instances' if args.scene == 'instanced' else 'meshes, each distinct'} + 10 emissive discs)") +
+                                   (f" {W}x{H}, RIS project: {RIS_TOT} candidates per pixel, {RIS_TESTS} drawn" if ris else
+                                    f" {W}x{H}, temporal + 3 spatial reuse passes, VIS_REUSE+BRDF"),
                        "instanced_triangles": int(sum(scene.arrays()["ComponentDatas"][o["bvStartIndex"]][1]
                                                       for o in scene.arrays()["SceneObjects"])),
                        "resolution": [W, H], "triangles": int(len(scene.arrays()['Triangles'])),
@@ -206,7 +238,7 @@ def main():
 class SingleRunner:
     def __init__(self, rt, scene, cfg):
         self.ctx = rt.RtContext(0)
-        self.drv = rt.Driver(self.ctx, cfg, scene)
+        self.drv = (rt.RisDriver if isinstance(cfg, rt.RisConfig) else rt.Driver)(self.ctx, cfg, scene)
         self.npx = cfg.Resolution[0] * cfg.Resolution[1]
 
     def render_frame(self):

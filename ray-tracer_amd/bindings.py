@@ -202,6 +202,8 @@ def host_lib():
             "rth_mg_destroy": (None, [vp]), "rth_mg_last_error": (cs, [vp]), "rth_mg_bounds": (ci, [vp, C.POINTER(ci)]),
             "rth_mg_render_frames": (ci, [vp, ci]), "rth_mg_loopback": (ci, [vp, ci, ci, ci]),
             "rth_mg_phase": (ci, [vp, ci]), "rth_mg_plan": (ci, [vp, ci, vp, ci]),
+            "rth_mg_create_ris": (vp, [vp, ci, ci, C.POINTER(ci), C.c_char_p, C.c_char_p, ci]),
+            "rth_ris_main_ctx": (vp, [vp]), "rth_ris_main_resolution": (ci, [vp, C.POINTER(ci)]),
             "rth_ris_default_config": (None, [C.POINTER(RisConfig)]), "rth_ris_camera_transform": (None, [fp, fp]),
             "rth_ris_main_create": (vp, [vp, C.POINTER(RisConfig), vp, ci, ci]), "rth_ris_main_destroy": (None, [vp]),
             "rth_ris_main_last_error": (cs, [vp]), "rth_ris_main_render_frame": (ci, [vp]),

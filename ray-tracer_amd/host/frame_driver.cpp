@@ -436,7 +436,10 @@ const int NCCL_UINT8 = 1;  // ncclUint8 / ncclChar share the value 1 and 0; byte
 }  // namespace
 
 struct rth_mg_s {
-    rth_main m = nullptr;
+    rth_main m = nullptr;        // the ReSTIR driver, or
+    rth_ris_main ris = nullptr;  // the RIS driver (no cross-pixel reads: no halo, only the gather)
+    rt_ctx ctx = nullptr;
+    int W = 0, H = 0, iterations = 0, blur = 0;
     int rank = 0, world = 1;
     std::vector<int> bounds;
     Rccl::comm_t comm = nullptr;
@@ -479,37 +482,57 @@ int rth_mg_unique_id(unsigned char out[128]) {
     return 0;
 }
 
-rth_mg rth_mg_create(rth_main m, int rank, int world, const int* bounds, const unsigned char uniqueId[128], char* err, int errLen) {
-    auto fail = [&](const std::string& msg) { if (err && errLen > 0) snprintf(err, (size_t)errLen, "%s", msg.c_str()); return (rth_mg) nullptr; };
-    if (!m || world < 1 || rank < 0 || rank >= world) return fail("bad arguments");
-    rth_mg g = new rth_mg_s;
-    g->m = m; g->rank = rank; g->world = world;
+namespace {
+rth_mg mgCreate(rth_mg g, int rank, int world, const int* bounds, const unsigned char uniqueId[128], char* err, int errLen) {
+    auto fail = [&](const std::string& msg) { if (err && errLen > 0) snprintf(err, (size_t)errLen, "%s", msg.c_str()); delete g; return (rth_mg) nullptr; };
+    if (!g->ctx || world < 1 || rank < 0 || rank >= world) return fail("bad arguments");
+    g->rank = rank; g->world = world;
     g->bounds.resize((size_t)world + 1);
     if (bounds) {  // the caller's cuts (e.g. balanced by cost); every rank must pass the same ones
         for (int r = 0; r <= world; r++) g->bounds[(size_t)r] = bounds[r];
-        bool ok = bounds[0] == 0 && bounds[world] == m->cfg.Resolution[1];
+        bool ok = bounds[0] == 0 && bounds[world] == g->H;
         for (int r = 0; r < world; r++) ok = ok && bounds[r + 1] > bounds[r] && (bounds[r] % 8 == 0);
-        if (!ok) { delete g; return fail("band boundaries must start at 0, end at the image height, increase, and be multiples of 8"); }
-    } else if (rth_mg_band_bounds(m->cfg.Resolution[1], world, g->bounds.data()) != 0) { delete g; return fail("the image cannot be cut into that many bands of whole tiles"); }
-    const int total = rth_mg_halo_plan(m->cfg.SpatialReuseIterations, m->cfg.SpatialReuseBlur, nullptr, nullptr);
+        if (!ok) return fail("band boundaries must start at 0, end at the image height, increase, and be multiples of 8");
+    } else if (rth_mg_band_bounds(g->H, world, g->bounds.data()) != 0) return fail("the image cannot be cut into that many bands of whole tiles");
+    const int total = rth_mg_halo_plan(g->iterations, g->blur, nullptr, nullptr);
     for (int r = 0; r < world; r++)
-        if (world > 1 && g->bounds[(size_t)r + 1] - g->bounds[(size_t)r] < total) { delete g; return fail("a band is shorter than the halo: use fewer GPUs or a larger image"); }
+        if (world > 1 && g->bounds[(size_t)r + 1] - g->bounds[(size_t)r] < total) return fail("a band is shorter than the halo: use fewer GPUs or a larger image");
     // A communicator of one rank is legal (and lets a single GPU exercise the set-up).  Several ranks WITHOUT an id
     // get no communicator: such a rank can only be stepped with rth_mg_phase / rth_mg_plan, by a test that carries
     // the transfers out itself.
     if (uniqueId) {
-        if (!rccl().ok) { std::string w = rccl().why; delete g; return fail(w); }
+        if (!rccl().ok) return fail(rccl().why);
         Rccl::UniqueId id;
         memcpy(id.internal, uniqueId, 128);
         int rc = rccl().CommInitRank(&g->comm, world, id, rank);  // on the device current in this thread (rt_create made it so)
-        if (rc != 0) { std::string w = std::string("ncclCommInitRank: ") + rccl().GetErrorString(rc); delete g; return fail(w); }
+        if (rc != 0) return fail(std::string("ncclCommInitRank: ") + rccl().GetErrorString(rc));
     }
     return g;
 }
+}  // namespace
+
+rth_mg rth_mg_create(rth_main m, int rank, int world, const int* bounds, const unsigned char uniqueId[128], char* err, int errLen) {
+    rth_mg g = new rth_mg_s;
+    if (m) {
+        g->m = m; g->ctx = m->ctx;
+        g->W = m->cfg.Resolution[0]; g->H = m->cfg.Resolution[1];
+        g->iterations = m->cfg.SpatialReuseIterations; g->blur = m->cfg.SpatialReuseBlur;
+    }
+    return mgCreate(g, rank, world, bounds, uniqueId, err, errLen);
+}
+rth_mg rth_mg_create_ris(rth_ris_main m, int rank, int world, const int* bounds, const unsigned char uniqueId[128], char* err, int errLen) {
+    rth_mg g = new rth_mg_s;
+    int res[2] = {0, 0};
+    if (m && rth_ris_main_resolution(m, res) == 0) {
+        g->ris = m; g->ctx = rth_ris_main_ctx(m);
+        g->W = res[0]; g->H = res[1];
+    }
+    return mgCreate(g, rank, world, bounds, uniqueId, err, errLen);
+}
 void rth_mg_destroy(rth_mg g) {
     if (!g) return;
-    if (g->comm) { rt_sync(g->m->ctx); rccl().CommDestroy(g->comm); }
-    rt_set_row_band(g->m->ctx, 0, 0);
+    if (g->comm) { rt_sync(g->ctx); rccl().CommDestroy(g->comm); }
+    rt_set_row_band(g->ctx, 0, 0);
     delete g;
 }
 const char* rth_mg_last_error(rth_mg g) { return g ? g->err.c_str() : "null"; }
@@ -522,7 +545,7 @@ int rth_mg_bounds(rth_mg g, int* out) {
 // Self-test of the transfer path on one rank: rows [src0, src1) of the Candidates buffer and of the depth texture are
 // sent to, and received from, this same rank with the RCCL calls the frame loop uses, landing at row dst0.
 int rth_mg_loopback(rth_mg g, int src0, int src1, int dst0) {
-    if (!g || !g->comm || src1 <= src0) return -1;
+    if (!g || !g->m || !g->comm || src1 <= src0) return -1;
     rth_main m = g->m;
     rt_ctx ctx = m->ctx;
     const int W = m->cfg.Resolution[0];
@@ -550,14 +573,14 @@ int rth_mg_loopback(rth_mg g, int src0, int src1, int dst0) {
 namespace {
 
 void mgCheck(rth_mg g, int rc, const char* what) {
-    if (rc < 0) throw DriverError{std::string(what) + ": " + rt_last_error(g->m->ctx)};
+    if (rc < 0) throw DriverError{std::string(what) + ": " + rt_last_error(g->ctx)};
 }
 // Appends the transfers of rows [r0, r1) of a reservoir buffer and/or a texture to or from `peer`.
 void mgRows(rth_mg g, std::vector<rth_xfer>& plan, bool send, rt_buffer buf, rt_texture tex, int r0, int r1, int peer) {
     if (r1 <= r0) return;
     rt_segment seg[5];
     int cnt = 0;
-    if (buf) mgCheck(g, rt_buffer_map_rows(buf, g->m->cfg.Resolution[0], r0, r1, seg, &cnt), "rt_buffer_map_rows");
+    if (buf) mgCheck(g, rt_buffer_map_rows(buf, g->W, r0, r1, seg, &cnt), "rt_buffer_map_rows");
     if (tex) { mgCheck(g, rt_texture_map_rows(tex, r0, r1, &seg[cnt]), "rt_texture_map_rows"); cnt++; }
     for (int k = 0; k < cnt; k++) plan.push_back({send ? 1 : 0, peer, seg[k].ptr, seg[k].bytes});
 }
@@ -565,10 +588,10 @@ void mgRows(rth_mg g, std::vector<rth_xfer>& plan, bool send, rt_buffer buf, rt_
 // to both neighbours, theirs come here, `total` rows deep.
 void mgPlanHalo(rth_mg g, std::vector<rth_xfer>& plan) {
     rth_main m = g->m;
-    const int rank = g->rank, world = g->world, H = m->cfg.Resolution[1];
+    if (!m || g->iterations <= 0) return;
+    const int rank = g->rank, world = g->world, H = g->H;
     const int b0 = g->bounds[(size_t)rank], b1 = g->bounds[(size_t)rank + 1];
-    const int total = rth_mg_halo_plan(m->cfg.SpatialReuseIterations, m->cfg.SpatialReuseBlur, nullptr, nullptr);
-    if (m->cfg.SpatialReuseIterations <= 0) return;
+    const int total = rth_mg_halo_plan(g->iterations, g->blur, nullptr, nullptr);
     rt_buffer cand = m->CandidateBuffer.h;
     rt_texture depth = m->DepthBufferTexture.h;
     if (rank > 0) {
@@ -582,20 +605,31 @@ void mgPlanHalo(rth_mg g, std::vector<rth_xfer>& plan) {
 }
 // The displayed image is completed on rank 0.
 void mgPlanGather(rth_mg g, std::vector<rth_xfer>& plan) {
-    rth_main m = g->m;
+    rt_texture result = g->m ? g->m->RTResultTexture.h : rth_ris_main_texture(g->ris, "Result");
+    if (!result) throw DriverError{"the Result texture does not exist"};
     if (g->rank == 0) {
-        for (int r = 1; r < g->world; r++) mgRows(g, plan, false, nullptr, m->RTResultTexture.h, g->bounds[(size_t)r], g->bounds[(size_t)r + 1], r);
+        for (int r = 1; r < g->world; r++) mgRows(g, plan, false, nullptr, result, g->bounds[(size_t)r], g->bounds[(size_t)r + 1], r);
     } else {
-        mgRows(g, plan, true, nullptr, m->RTResultTexture.h, g->bounds[(size_t)g->rank], g->bounds[(size_t)g->rank + 1], 0);
+        mgRows(g, plan, true, nullptr, result, g->bounds[(size_t)g->rank], g->bounds[(size_t)g->rank + 1], 0);
     }
 }
 // Phase 0 of a frame: everything before the halo exchange.  Phase 1: everything after it.
 void mgPhase(rth_mg g, int phase) {
     rth_main m = g->m;
-    rt_ctx ctx = m->ctx;
-    const int rank = g->rank, world = g->world, H = m->cfg.Resolution[1];
+    rt_ctx ctx = g->ctx;
+    const int rank = g->rank, world = g->world, H = g->H;
     const int b0 = g->bounds[(size_t)rank], b1 = g->bounds[(size_t)rank + 1];
     auto rows = [&](int r0, int r1) { mgCheck(g, rt_set_row_band(ctx, r0, r1), "rt_set_row_band"); };
+    if (g->ris) {  // the whole RIS frame precedes its only transfer, the gather
+        if (phase != 0) return;
+        auto ris = [&](int rc) { if (rc != 0) throw DriverError{rth_ris_main_last_error(g->ris)}; };
+        rows(b0, b1);
+        ris(rth_ris_main_update_per_frame(g->ris));
+        ris(rth_ris_main_run_stage(g->ris, 0));
+        ris(rth_ris_main_run_stage(g->ris, 1));
+        ris(rth_ris_main_run_post_processing(g->ris));
+        return;
+    }
     m->CreateTextures();
     if (phase == 0) {
         rows(b0, b1);
@@ -623,7 +657,7 @@ void mgPhase(rth_mg g, int phase) {
 void mgRun(rth_mg g, const std::vector<rth_xfer>& plan) {
     if (plan.empty()) return;
     auto nccl = [&](int rc, const char* what) { if (rc != 0) throw DriverError{std::string(what) + ": " + rccl().GetErrorString(rc)}; };
-    void* stream = rt_stream(g->m->ctx);
+    void* stream = rt_stream(g->ctx);
     nccl(rccl().GroupStart(), "ncclGroupStart");
     for (const auto& x : plan) {
         if (x.send) nccl(rccl().Send(x.ptr, x.bytes, NCCL_UINT8, x.peer, g->comm, stream), "ncclSend");
@@ -665,7 +699,7 @@ int rth_mg_plan(rth_mg g, int which, rth_xfer* out, int cap) {
     if (!g || which < 0 || which > 1) return -1;
     std::vector<rth_xfer> plan;
     try {
-        g->m->CreateTextures();
+        if (g->m) g->m->CreateTextures();
         if (which == 0) mgPlanHalo(g, plan); else mgPlanGather(g, plan);
     } catch (const DriverError& e) { g->err = e.msg; return -1; }
     if ((int)plan.size() > cap || (!out && !plan.empty())) return -1;

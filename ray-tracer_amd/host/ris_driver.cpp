@@ -291,6 +291,12 @@ int rth_ris_main_render_frame(rth_ris_main m) {
     });
 }
 int rth_ris_main_frame_count(rth_ris_main m) { return m ? m->FrameCount : -1; }
+rt_ctx rth_ris_main_ctx(rth_ris_main m) { return m ? m->ctx : nullptr; }
+int rth_ris_main_resolution(rth_ris_main m, int out[2]) {
+    if (!m || !out) return -1;
+    out[0] = m->cfg.Resolution[0]; out[1] = m->cfg.Resolution[1];
+    return 0;
+}
 
 int rth_ris_main_scene(rth_ris_main m, rth_ris_scene_data* out) {
     if (!m || !out) return -1;

@@ -232,6 +232,12 @@ int rth_ris_main_update_per_frame(rth_ris_main m);
 int rth_ris_main_run_stage(rth_ris_main m, int stage); /* 0 GenerateCandidates, 1 TraceRays */
 int rth_ris_main_run_post_processing(rth_ris_main m);
 int rth_ris_main_frame_count(rth_ris_main m);
+rt_ctx rth_ris_main_ctx(rth_ris_main m);
+int rth_ris_main_resolution(rth_ris_main m, int out[2]);
+/* One rank of the banded RIS frame loop: the RIS kernels read only their own pixel, so a frame is the rank's band of
+ * GenerateCandidates, TraceRays and AccumulateFrames followed by the gather of Result on rank 0; no halo.  The
+ * handle is used with the same rth_mg_* calls as the ReSTIR one (rth_mg_loopback excepted). */
+rth_mg rth_mg_create_ris(rth_ris_main m, int rank, int world, const int* bounds, const unsigned char uniqueId[128], char* err, int errLen);
 
 typedef struct {
     const rt_ris_tri* Tris; int64_t nTris;               /* worldNormal = 0: CalcTriNormals fills it on the device */

@@ -157,6 +157,19 @@ def render_frame_banded(stages, store, rank, world, bounds, height, iterations, 
     _gather(store, ["Result"], rank, world, bounds)   # the displayed image; the running sum stays per band
 
 
+def render_ris_frame_banded(stages, store, rank, world, bounds):
+    """One frame of the RIS project (BVH_RIS_DL/Assets/Scripts/Main.cs:132-144, 319-376) on this rank's band.  Its
+    kernels read only their own pixel, so there is nothing to exchange; rank 0 collects the displayed image.
+
+    `stages` provides set_rows(r0, r1), update_per_frame(), generate_candidates(), trace_rays(), accumulate()."""
+    stages.set_rows(bounds[rank], bounds[rank + 1])
+    stages.update_per_frame()
+    stages.generate_candidates()
+    stages.trace_rays()
+    stages.accumulate()
+    _gather(store, ["Result"], rank, world, bounds)
+
+
 # ------------------------------------------------------------------------------------------------- GPU side
 class _DevicePtr:
     def __init__(self, ptr, nbytes):
@@ -297,10 +310,12 @@ class RcclRunner:
         self.rt, self.rank, self.world = rt, rank, world
         self.host = rt.host_lib()
         self.ctx = rt.RtContext(local_rank)
-        self.drv = rt.Driver(self.ctx, cfg, scene)
+        # an RisConfig selects the RIS project's frame (no halo: its kernels read only their own pixel)
+        self.ris = isinstance(cfg, rt.RisConfig)
+        self.drv = rt.RisDriver(self.ctx, cfg, scene) if self.ris else rt.Driver(self.ctx, cfg, scene)
         self.W, self.H = cfg.Resolution[0], cfg.Resolution[1]
         bounds = None
-        if balance and world > 1:
+        if balance and world > 1 and not self.ris:
             # Frame 0 is rendered in full by every rank: all ranks then hold the same depth buffer, derive the same
             # per-row cost from it and so agree on cost-balanced bands without exchanging anything; the frames that
             # follow are banded and continue the same sequence a single GPU would render.
@@ -322,7 +337,8 @@ class RcclRunner:
                 uid = box[0]
         err = C.create_string_buffer(512)
         cb = (C.c_int * (world + 1))(*bounds) if bounds else None
-        self.h = self.host.rth_mg_create(self.drv.h, rank, world, cb, uid, err, 512)
+        create = self.host.rth_mg_create_ris if self.ris else self.host.rth_mg_create
+        self.h = create(self.drv.h, rank, world, cb, uid, err, 512)
         if not self.h:
             raise RuntimeError("rth_mg_create: " + err.value.decode())
         b = (C.c_int * (world + 1))()

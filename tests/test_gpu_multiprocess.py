@@ -186,3 +186,67 @@ def test_native_schedule_many_ranks_in_process(scene_small, world, res, balanced
             d.close()
         for c in ctxs:
             c.close()
+
+
+@pytest.mark.parametrize("world,res", [(2, (64, 48)), (5, (96, 120))])
+def test_native_ris_schedule_many_ranks_in_process(scene_small, world, res):
+    """The banded RIS frame loop (rth_mg_create_ris) for several ranks held in this process: phase 0 renders the
+    band, plan 0 (the halo) is empty, plan 1 is the gather of Result, carried out here with device copies."""
+    import ctypes as C
+    import harness as h
+    rt = h.rt
+    bindings = importlib.import_module("ray-tracer_amd.bindings")
+    hip = C.CDLL("libamdhip64.so")
+    hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    hip.hipMemcpy.restype = C.c_int
+    W, H = res
+    cfg = h.small_ris_config(W, H)
+    tot = cfg.SceneObjectCandidatesNum * cfg.TriCandidatesNum
+    host = rt.host_lib()
+    ctxs = [rt.RtContext(0) for _ in range(world + 1)]
+    drvs = [rt.RisDriver(c, cfg, scene_small) for c in ctxs]
+    ref_ctx, ref = ctxs[world], drvs[world]
+    ranks = []
+    err = C.create_string_buffer(512)
+    try:
+        for r in range(world):
+            g = host.rth_mg_create_ris(drvs[r].h, r, world, None, None, err, 512)
+            assert g, err.value.decode()
+            ranks.append(g)
+        b = (C.c_int * (world + 1))()
+        host.rth_mg_bounds(ranks[0], b)
+        cuts = list(b)
+        for frame in range(2):
+            plans = []
+            for g in ranks:
+                assert host.rth_mg_phase(g, 0) == 0, host.rth_mg_last_error(g)
+                assert host.rth_mg_plan(g, 0, None, 0) == 0
+                assert host.rth_mg_phase(g, 1) == 0
+                buf = (bindings.Xfer * 16)()
+                n = host.rth_mg_plan(g, 1, buf, 16)
+                assert n == (world - 1 if g is ranks[0] else 1), host.rth_mg_last_error(g)
+                plans.append([buf[i] for i in range(n)])
+            for c in ctxs[:world]:
+                c.sync()
+            for r in range(1, world):
+                (s,) = plans[r]
+                d = [x for x in plans[0] if x.peer == r][0]
+                assert s.send and s.peer == 0 and not d.send and s.bytes == d.bytes == (cuts[r + 1] - cuts[r]) * W * 16
+                assert hip.hipMemcpy(d.ptr, s.ptr, s.bytes, 3) == 0
+            ref.render_frame()
+            ref_ctx.sync()
+            assert np.array_equal(h.bits(drvs[0].texture("Result")), h.bits(ref.texture("Result"))), frame
+            for r in range(world):
+                lo, hi = cuts[r], cuts[r + 1]
+                assert np.array_equal(h.bits(drvs[r].texture("AccumulatedResult")[lo:hi]), h.bits(ref.texture("AccumulatedResult")[lo:hi])), (frame, r)
+                assert np.array_equal(h.bits(drvs[r].buffer("Candidates")[lo * W * tot:hi * W * tot]),
+                                      h.bits(ref.buffer("Candidates")[lo * W * tot:hi * W * tot])), (frame, r)
+                assert np.array_equal(h.bits(drvs[r].buffer("HitInfos")[lo * W:hi * W]), h.bits(ref.buffer("HitInfos")[lo * W:hi * W])), (frame, r)
+        assert ref.texture("Result")[..., :3].any()
+    finally:
+        for g in ranks:
+            host.rth_mg_destroy(g)
+        for d in drvs:
+            d.close()
+        for c in ctxs:
+            c.close()

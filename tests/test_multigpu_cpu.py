@@ -86,6 +86,38 @@ def _worker(rank, world, port, res, frames, out_dir):
         dist.destroy_process_group()
 
 
+def _ris_worker(rank, world, port, res, frames, out_dir):
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    sys.path.insert(0, ROOT)
+    import harness as h
+    mg = importlib.import_module("ray-tracer_amd.multigpu")
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    try:
+        scene = h.rt.build_scene_s0(subdivide=False, threads=1)
+        cfg = h.small_ris_config(*res)
+        bounds = mg.band_bounds(res[1], world)
+        banded = h.RisOracleRenderer(scene.arrays(), cfg, threads=1, records=False)
+        full = h.RisOracleRenderer(scene.arrays(), cfg, threads=1, records=False)
+        banded.set_rows = banded.set_band
+        store = NumpyRowStore(banded)
+        W = res[0]
+        tot = cfg.SceneObjectCandidatesNum * cfg.TriCandidatesNum
+        for frame in range(frames):
+            mg.render_ris_frame_banded(banded, store, rank, world, bounds)
+            full.render_frame()
+            r0, r1 = bounds[rank], bounds[rank + 1]
+            assert np.array_equal(h.bits(banded.buf["HitInfos"][r0 * W:r1 * W]), h.bits(full.buf["HitInfos"][r0 * W:r1 * W])), (rank, frame)
+            assert np.array_equal(h.bits(banded.buf["Candidates"][r0 * W * tot:r1 * W * tot]),
+                                  h.bits(full.buf["Candidates"][r0 * W * tot:r1 * W * tot])), (rank, frame)
+            assert np.array_equal(h.bits(banded.tex["AccumulatedResult"][r0:r1]), h.bits(full.tex["AccumulatedResult"][r0:r1]))
+            if rank == 0:
+                assert np.array_equal(h.bits(banded.tex["Result"]), h.bits(full.tex["Result"])), frame
+        assert full.tex["Result"][..., :3].any()
+        open(os.path.join(out_dir, f"ok{rank}"), "w").write("ok")
+    finally:
+        dist.destroy_process_group()
+
+
 def _free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -98,6 +130,12 @@ def _free_port():
 def test_banded_equals_full_frame(tmp_path, world, res):
     mp.spawn(_worker, args=(world, _free_port(), res, 3, str(tmp_path)), nprocs=world, join=True)
     assert all((tmp_path / f"ok{r}").exists() for r in range(world))
+
+
+def test_ris_banded_equals_full_frame(tmp_path):
+    """The RIS project's frame on two ranks: bands and the gather only (its kernels read no other pixel)."""
+    mp.spawn(_ris_worker, args=(2, _free_port(), (64, 48), 2, str(tmp_path)), nprocs=2, join=True)
+    assert all((tmp_path / f"ok{r}").exists() for r in range(2))
 
 
 def test_band_bounds_and_halo():
