@@ -33,16 +33,22 @@ constexpr int ENTRY_INLINE_MAX_START = (1 << 26) - 1;
 //   q0 = v0.xyz, N.x   q1 = edgeAB.xyz, N.y   q2 = edgeAC.xyz, N.z   q3 = localNormal.xyz, 0
 // with N = cross(edgeAB, edgeAC), computed with the same fp32 operations the intersection routine would use.
 
-// Per-pixel records are kept as planes of 16-byte elements (structure of arrays): a 52-byte reservoir or
-// hit record of `count` pixels is stored as three float4 planes followed by one float plane, in the same
-// 52*count bytes.  Every access is then one coalesced 16-byte-per-lane load or store.
-//   reservoir: p0 = dir.xyz, chosenWeight   p1 = hitPoint.xyz, totWeights   p2 = normal.xyz, totCandidates   p3 = brdf
+// The per-pixel hit records are kept as planes of 16-byte elements (structure of arrays): the 52-byte record of
+// `count` pixels is stored as three float4 planes followed by one float plane, in the same 52*count bytes.  Every
+// access is then one coalesced 16-byte-per-lane load or store (a hit record is only ever read at the thread's own pixel).
 //   hit info : p0 = hitPoint.xyz, dst       p1 = normal.xyz, materialIndex  p2 = incomingDir.xyz, uv.x       p3 = uv.y
 struct Planes {
     float4* p0;
     float4* p1;
     float4* p2;
     float* p3;
+    int64_t count;
+};
+// Reservoirs are also GATHERED, from random neighbouring pixels (SpatialReusePass reads nine per pixel and pass): each
+// is one aligned 64-byte record, so a gathered reservoir costs one cache line instead of four.
+//   q0 = dir.xyz, chosenWeight   q1 = hitPoint.xyz, totWeights   q2 = normal.xyz, totCandidates   q3 = brdf, 0, 0, 0
+struct Recs {
+    float4* q;  // 4 per pixel
     int64_t count;
 };
 
@@ -69,7 +75,8 @@ struct KParams {
     int stackDepth;  // dwords of LDS stack per lane
     Tex atlas, env;
     // per-pixel state
-    Planes hit, cand, candB, temporal;
+    Planes hit;
+    Recs cand, candB, temporal;
     Tex result, accumulated, debugOverlay, depth, normals, hitA, hitB;
     // constants
     uint32_t MaxBVHDepth;

@@ -30,7 +30,14 @@ constexpr int WAVES_PER_BLOCK = 4;
 #ifndef RT_MIN_WAVES
 #define RT_MIN_WAVES 1
 #endif
+#ifndef RT_TRAV
+#define RT_TRAV 3
+#endif
+#if RT_TRAV == 4
+#define TRAVERSE traverse4
+#else
 #define TRAVERSE traverse3
+#endif
 
 struct v2 { float x, y; };
 struct v3 { float x, y, z; };
@@ -417,6 +424,107 @@ DEV void traverse3(const KParams& P, const v3 wpos, const v3 wdir, const v3 winv
     while (__builtin_amdgcn_ballot_w64(alive) != 0) travTrip<INSTR, RIS>(P, s, t, stk, alive);
 }
 
+// ---- Variant with ONE 64-byte fetch per trip: a lane at an internal node fetches its wide record, a lane inside a
+// leaf fetches its next baked triangle, through the same four loads; only the arithmetic afterwards differs per lane.
+// A trip then costs one memory latency whatever mix of lanes the wave holds, and no lane waits for a phase.
+struct TravState4 : TravState { int triCur, triEnd; };
+
+// Turns a held leaf entry into a run of triangles (inside an object) or of scene objects (scene level).
+template <bool INSTR>
+DEV void travDecodeLeaf(const KParams& P, TravState4& s, Trav& t, const uint32_t* stk) {
+    const uint32_t e = s.e;
+    int start, count;
+    if (e & ENTRY_LEAF) {
+        start = (int)(e & (uint32_t)ENTRY_INLINE_MAX_START);
+        count = (int)((e >> 26) & 31u);
+        if (INSTR) { t.hash = (t.hash ^ (uint32_t)start) * 16777619u; t.hash = (t.hash ^ (uint32_t)count) * 16777619u; }
+    } else {
+        const rt_bv* bv = &P.BVs[e & ENTRY_INDEX_MASK];
+        int a = bv->indexA, b = bv->indexB;
+        if (INSTR) { t.hash = (t.hash ^ (uint32_t)a) * 16777619u; t.hash = (t.hash ^ (uint32_t)b) * 16777619u; }
+        start = a < 0 ? -a : a;
+        count = b < 0 ? -b : b;
+    }
+    if (INSTR) t.iters++;
+    if (s.objBase < 0) {  // scene-level leaf: its objects are entered one by one by the service step
+        s.objCur = start;
+        s.objEnd = start + count;
+        s.e = ENTRY_NONE;
+    } else if (count > 0) {
+        s.triCur = start;
+        s.triEnd = start + count;
+        s.e = ENTRY_NONE;
+    } else {
+        travPop<INSTR>(P, s, t, stk);
+    }
+}
+
+template <bool INSTR, bool RIS>
+DEV void travTrip4(const KParams& P, TravState4& s, Trav& t, uint32_t* stk, bool& alive) {
+    if (alive && s.e != ENTRY_NONE && (s.e & LEAF_BITS) != 0) travDecodeLeaf<INSTR>(P, s, t, stk);
+    if (alive && s.e == ENTRY_NONE && s.triCur >= s.triEnd) alive = travService<INSTR, RIS>(P, s, t, stk);
+    if (alive && s.e != ENTRY_NONE && (s.e & LEAF_BITS) != 0) travDecodeLeaf<INSTR>(P, s, t, stk);
+    const bool isTri = alive && s.e == ENTRY_NONE && s.triCur < s.triEnd;
+    const bool isInt = alive && s.e != ENTRY_NONE && (s.e & LEAF_BITS) == 0;
+    if (!(isTri || isInt)) return;
+    const float4* rec = isInt ? P.wide + (int64_t)s.e * 4 : P.btri + (int64_t)s.triCur * 4;
+    const float4 q0 = rec[0], q1 = rec[1], q2 = rec[2], q3 = rec[3];
+    if (isInt) {  // RS:195-214
+        const uint32_t e = s.e;
+        if (INSTR) { t.iters++; t.hash = (t.hash ^ (0x80000000u | e)) * 16777619u; }
+        const float dstA = RIS ? RayBVIntersectDiv(s.rpos, s.rdir, V3(q0.x, q0.y, q0.z), V3(q0.w, q1.x, q1.y))
+                               : RayBVIntersect(s.rpos, s.rinv, V3(q0.x, q0.y, q0.z), V3(q0.w, q1.x, q1.y));
+        const float dstB = RIS ? RayBVIntersectDiv(s.rpos, s.rdir, V3(q1.z, q1.w, q2.x), V3(q2.y, q2.z, q2.w))
+                               : RayBVIntersect(s.rpos, s.rinv, V3(q1.z, q1.w, q2.x), V3(q2.y, q2.z, q2.w));
+        t.bvChecks += 2;
+        const uint32_t eA = __float_as_uint(q3.x), eB = __float_as_uint(q3.y);
+        const bool aFirst = dstA < dstB;  // the nearer child is visited first
+        const uint32_t eNear = aFirst ? eA : eB, eFar = aFirst ? eB : eA;
+        const bool nearHit = (aFirst ? dstA : dstB) < s.best, farHit = (aFirst ? dstB : dstA) < s.best;
+        if (nearHit) {
+            if (farHit) { if (s.sp < P.stackDepth) stk[s.sp * 64] = eFar; s.sp++; }
+            s.e = eNear;
+            if (INSTR) t.pops++;
+        } else if (farHit) {
+            s.e = eFar;
+            if (INSTR) t.pops++;
+        } else {
+            travPop<INSTR>(P, s, t, stk);
+        }
+    } else {      // one triangle of the leaf's run, RS:179-193
+        const int triIndex = s.triCur;
+        if (INSTR) t.triIters++;
+        const bool facing = RIS || dot(V3(q3.x, q3.y, q3.z), s.rdir) <= 0;
+        if (facing) {
+            // RayTriangleIntersect, RS:119-146
+            v3 edgeAB = V3(q1.x, q1.y, q1.z), edgeAC = V3(q2.x, q2.y, q2.z);
+            v3 normalVector = V3(q0.w, q1.w, q2.w);
+            v3 ao = s.rpos - V3(q0.x, q0.y, q0.z);
+            v3 dao = cross(ao, s.rdir);
+            float determinant = -dot(s.rdir, normalVector);
+            float invDet = 1 / determinant;
+            float dst = dot(ao, normalVector) * invDet;
+            float u = dot(edgeAC, dao) * invDet;
+            float v = -dot(edgeAB, dao) * invDet;
+            float w = 1 - u - v;
+            bool didHit = determinant >= 1E-8f && dst >= 0 && u >= 0 && v >= 0 && w >= 0;
+            t.triChecks++;
+            if (didHit && dst < s.best) { s.best = dst; s.localU = u; s.localV = v; s.localTri = triIndex; }
+        }
+        s.triCur = triIndex + 1;
+        if (s.triCur >= s.triEnd) travPop<INSTR>(P, s, t, stk);
+    }
+}
+
+template <bool INSTR, bool RIS = false>
+DEV void traverse4(const KParams& P, const v3 wpos, const v3 wdir, const v3 winv, uint32_t* stk, Trav& t) {
+    TravState4 s;
+    travBegin<INSTR>(P, s, t, wpos, wdir, winv);
+    s.triCur = 0; s.triEnd = 0;
+    bool alive = true;
+    while (__builtin_amdgcn_ballot_w64(alive) != 0) travTrip4<INSTR, RIS>(P, s, t, stk, alive);
+}
+
 // Shading data of a traversal result, as TraverseSceneBVH leaves it in hitInfo (RS:248-258).
 struct HitInfo { float dst; v3 hitPoint; v2 uv; v3 normal; v3 incomingDir; int materialIndex; };
 DEV HitInfo resolveHit(const KParams& P, const Trav& t, v3 wpos, v3 wdir) {
@@ -494,22 +602,26 @@ DEV Reservoir emptyReservoir() {
     r.brdf = r.chosenWeight = r.totWeights = r.totCandidates = 0;
     return r;
 }
-DEV void storeReservoir(const Planes& pl, int64_t i, const Reservoir& r) {
-    pl.p0[i] = make_float4(r.dir.x, r.dir.y, r.dir.z, r.chosenWeight);
-    pl.p1[i] = make_float4(r.hitPoint.x, r.hitPoint.y, r.hitPoint.z, r.totWeights);
-    pl.p2[i] = make_float4(r.normal.x, r.normal.y, r.normal.z, r.totCandidates);
-    pl.p3[i] = r.brdf;
+DEV void storeReservoir(const Recs& rc, int64_t i, const Reservoir& r) {
+    float4* q = rc.q + i * 4;
+    q[0] = make_float4(r.dir.x, r.dir.y, r.dir.z, r.chosenWeight);
+    q[1] = make_float4(r.hitPoint.x, r.hitPoint.y, r.hitPoint.z, r.totWeights);
+    q[2] = make_float4(r.normal.x, r.normal.y, r.normal.z, r.totCandidates);
+    q[3] = make_float4(r.brdf, 0.0f, 0.0f, 0.0f);
 }
-// index beyond the buffer -> zero reservoir
-DEV Reservoir loadReservoir(const Planes& pl, int64_t i) {
-    if (i < 0 || i >= pl.count) return emptyReservoir();
-    float4 a = pl.p0[i], b = pl.p1[i], c = pl.p2[i];
+DEV Reservoir unpackReservoir(float4 a, float4 b, float4 c, float4 d) {
     Reservoir r;
     r.dir = V3(a.x, a.y, a.z); r.chosenWeight = a.w;
     r.hitPoint = V3(b.x, b.y, b.z); r.totWeights = b.w;
     r.normal = V3(c.x, c.y, c.z); r.totCandidates = c.w;
-    r.brdf = pl.p3[i];
+    r.brdf = d.x;
     return r;
+}
+// index beyond the buffer -> zero reservoir
+DEV Reservoir loadReservoir(const Recs& rc, int64_t i) {
+    if (i < 0 || i >= rc.count) return emptyReservoir();
+    const float4* q = rc.q + i * 4;
+    return unpackReservoir(q[0], q[1], q[2], q[3]);
 }
 DEV float depthAt(const KParams& P, int x, int y) {
     if (x < 0 || y < 0 || x >= P.ResX || y >= P.ResY) return 0.0f;
@@ -765,8 +877,8 @@ __global__ __launch_bounds__(256) void k_spatial(const KParams P) {
         const uint32_t idx = (uint32_t)px.x, idy = (uint32_t)px.y;
         uint32_t state = idy * (uint32_t)P.ResX + idx + P.FrameRand;
         const uint32_t pixelBaseIndex = (uint32_t)P.ResX * idy + idx;
-        const Planes& src = P.ReuseBufferCycle ? P.cand : P.candB;
-        const Planes& dstb = P.ReuseBufferCycle ? P.candB : P.cand;
+        const Recs& src = P.ReuseBufferCycle ? P.cand : P.candB;
+        const Recs& dstb = P.ReuseBufferCycle ? P.candB : P.cand;
         const Reservoir base = loadReservoir(src, pixelBaseIndex);
         Reservoir sp = base;
         for (uint32_t k = 0; k < P.TemporalCandidatesNum; k++) {
@@ -775,9 +887,17 @@ __global__ __launch_bounds__(256) void k_spatial(const KParams P) {
             int offX = px.x + ox, offY = px.y + oy;
             // `any(offsetID) < 0` (RS:528) is always false: negative coordinates are not rejected; a negative x
             // wraps into the previous row through the unsigned pixel index, a negative y indexes out of range.
-            if (offX >= P.ResX || offY >= P.ResY || depthAt(P, offX, offY) == INF()) continue;
-            uint32_t pixelIndex = (uint32_t)P.ResX * (uint32_t)offY + (uint32_t)offX;
-            const Reservoir cand = loadReservoir(src, (int64_t)pixelIndex);
+            // The neighbour's depth and its reservoir are fetched together (the reservoir speculatively, from this
+            // pixel's own record when the neighbour's does not exist): one memory latency per neighbour, not two.
+            const bool inImage = !(offX >= P.ResX || offY >= P.ResY);
+            const uint32_t pixelIndex = (uint32_t)P.ResX * (uint32_t)offY + (uint32_t)offX;
+            const bool inBuffer = (int64_t)pixelIndex < src.count;  // index beyond the buffer -> zero reservoir
+            const int64_t li = inImage && inBuffer ? (int64_t)pixelIndex : (int64_t)pixelBaseIndex;
+            const float nDepth = depthAt(P, offX, offY);
+            const float4* cq = src.q + li * 4;
+            const float4 ca = cq[0], cb = cq[1], cc = cq[2], cd = cq[3];
+            if (!inImage || nDepth == INF()) continue;
+            const Reservoir cand = inBuffer ? unpackReservoir(ca, cb, cc, cd) : emptyReservoir();
             neighbours++;
             if (cand.dir.x == 0 || cand.dir.y == 0 || cand.dir.z == 0) continue;  // `all(dir) == 0`, RS:536
             float hitPointDiff = length(base.hitPoint - cand.hitPoint);
@@ -799,17 +919,26 @@ __global__ __launch_bounds__(256) void k_spatial(const KParams P) {
     if (P.stats && P.statsLevel >= 2) { waveAdd(P.stats + ST_ACTIVE, active ? 1u : 0u); waveAdd(P.stats + ST_NEIGHBOURS, neighbours); }
 }
 
-// TransferToOriginal (RS:575-582)
+// TransferToOriginal (RS:575-582).  A pure copy, so the wave moves its tile's records cooperatively: four adjacent
+// lanes copy the four quarters of one record, and every instruction covers two image rows of the tile as two runs of
+// 512 contiguous bytes (one lane per record would touch 32 cache lines per instruction).
 __global__ __launch_bounds__(256) void k_transfer(const KParams P) {
     const Pixel px = pixelOfThread(P);
     bool active = px.active;
     if (active) active = depthAt(P, px.x, px.y) != INF();
-    if (active) {
-        const int64_t i = (int64_t)((uint32_t)P.ResX * (uint32_t)px.y + (uint32_t)px.x);
-        P.cand.p0[i] = P.candB.p0[i];
-        P.cand.p1[i] = P.candB.p1[i];
-        P.cand.p2[i] = P.candB.p2[i];
-        P.cand.p3[i] = P.candB.p3[i];
+    const unsigned long long mask = __builtin_amdgcn_ballot_w64(active);
+    if (mask != 0) {
+        const int lane = (int)(threadIdx.x & 63);
+        const int x0 = px.x - (lane & 7), y0 = px.y - (lane >> 3);
+        const int col = (lane & 31) >> 2, piece = lane & 3;
+        #pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int row = 2 * k + (lane >> 5);
+            if ((mask >> (row * 8 + col)) & 1ull) {
+                const int64_t i = (int64_t)((uint32_t)P.ResX * (uint32_t)(y0 + row) + (uint32_t)(x0 + col));
+                P.cand.q[i * 4 + piece] = P.candB.q[i * 4 + piece];
+            }
+        }
     }
     if (P.stats && P.statsLevel >= 2) waveAdd(P.stats + ST_ACTIVE, active ? 1u : 0u);
 }
@@ -881,8 +1010,8 @@ __global__ __launch_bounds__(256, 5) void k_trace_rays(const KParams P) {
                         v2 wb = GenerateCandidateWeight(P, sqr(hitInfo.dst), fmaxf_(dot(hitInfo.normal, rdir), 0),
                                                         incomingDir, rdir, hitInfo.normal, metallicity, roughness,
                                                         material.brightness);
-                        P.temporal.p0[pixelIndex].w = wb.x;
-                        P.temporal.p3[pixelIndex] = wb.y;
+                        P.temporal.q[(int64_t)pixelIndex * 4].w = wb.x;      // chosenWeight
+                        P.temporal.q[(int64_t)pixelIndex * 4 + 3].x = wb.y;  // brdf
                     }
                 }
                 v3 col = matCol(P, material, hitInfo.uv);
@@ -1002,41 +1131,49 @@ __global__ void k_bake_tris(const rt_triangle* tris, int64_t nTris, const rt_ver
     out[i * 4 + 3] = make_float4(tri.localNormal.x, tri.localNormal.y, tri.localNormal.z, 0.0f);
 }
 
-// 52-byte records <-> planes (see rt_device.h).  Field order of both record types maps onto the planes as
-// {f0..f2 -> p0.xyz}, and the rest per `kind`: 0 = reservoir, 1 = hit info.
-__global__ void k_aos_to_planes(const float* aos, Planes pl, int kind) {
+// 52-byte ABI records <-> the internal layouts (see rt_device.h).
+// HitInfo: dst 0, hitPoint 1-3, uv 4-5, normal 6-8, incomingDir 9-11, materialIndex 12.
+__global__ void k_aos_to_planes(const float* aos, Planes pl) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= pl.count) return;
     const float* r = aos + i * 13;
-    if (kind == 0) {
-        pl.p0[i] = make_float4(r[0], r[1], r[2], r[10]);
-        pl.p1[i] = make_float4(r[3], r[4], r[5], r[11]);
-        pl.p2[i] = make_float4(r[6], r[7], r[8], r[12]);
-        pl.p3[i] = r[9];
-    } else {  // dst 0, hitPoint 1-3, uv 4-5, normal 6-8, incomingDir 9-11, materialIndex 12
-        pl.p0[i] = make_float4(r[1], r[2], r[3], r[0]);
-        pl.p1[i] = make_float4(r[6], r[7], r[8], r[12]);
-        pl.p2[i] = make_float4(r[9], r[10], r[11], r[4]);
-        pl.p3[i] = r[5];
-    }
+    pl.p0[i] = make_float4(r[1], r[2], r[3], r[0]);
+    pl.p1[i] = make_float4(r[6], r[7], r[8], r[12]);
+    pl.p2[i] = make_float4(r[9], r[10], r[11], r[4]);
+    pl.p3[i] = r[5];
 }
-__global__ void k_planes_to_aos(Planes pl, float* aos, int kind) {
+__global__ void k_planes_to_aos(Planes pl, float* aos) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= pl.count) return;
     float* r = aos + i * 13;
     float4 a = pl.p0[i], b = pl.p1[i], c = pl.p2[i];
     float d = pl.p3[i];
-    if (kind == 0) {
-        r[0] = a.x; r[1] = a.y; r[2] = a.z; r[10] = a.w;
-        r[3] = b.x; r[4] = b.y; r[5] = b.z; r[11] = b.w;
-        r[6] = c.x; r[7] = c.y; r[8] = c.z; r[12] = c.w;
-        r[9] = d;
-    } else {
-        r[1] = a.x; r[2] = a.y; r[3] = a.z; r[0] = a.w;
-        r[6] = b.x; r[7] = b.y; r[8] = b.z; r[12] = b.w;
-        r[9] = c.x; r[10] = c.y; r[11] = c.z; r[4] = c.w;
-        r[5] = d;
-    }
+    r[1] = a.x; r[2] = a.y; r[3] = a.z; r[0] = a.w;
+    r[6] = b.x; r[7] = b.y; r[8] = b.z; r[12] = b.w;
+    r[9] = c.x; r[10] = c.y; r[11] = c.z; r[4] = c.w;
+    r[5] = d;
+}
+// CandidateReservoir: dir 0-2, hitPoint 3-5, normal 6-8, brdf 9, chosenWeight 10, totWeights 11, totCandidates 12.
+__global__ void k_aos_to_recs(const float* aos, Recs rc) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= rc.count) return;
+    const float* r = aos + i * 13;
+    float4* q = rc.q + i * 4;
+    q[0] = make_float4(r[0], r[1], r[2], r[10]);
+    q[1] = make_float4(r[3], r[4], r[5], r[11]);
+    q[2] = make_float4(r[6], r[7], r[8], r[12]);
+    q[3] = make_float4(r[9], 0.0f, 0.0f, 0.0f);
+}
+__global__ void k_recs_to_aos(Recs rc, float* aos) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= rc.count) return;
+    float* r = aos + i * 13;
+    const float4* q = rc.q + i * 4;
+    float4 a = q[0], b = q[1], c = q[2], d = q[3];
+    r[0] = a.x; r[1] = a.y; r[2] = a.z; r[10] = a.w;
+    r[3] = b.x; r[4] = b.y; r[5] = b.z; r[11] = b.w;
+    r[6] = c.x; r[7] = c.y; r[8] = c.z; r[12] = c.w;
+    r[9] = d.x;
 }
 __global__ void k_rgba8_to_f32(const uint8_t* src, float4* dst, int64_t n) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;

@@ -92,7 +92,7 @@ __global__ __launch_bounds__(256, RT_MIN_WAVES) void k_ris_primary(const KParams
         const uint32_t rayIndex = ((uint32_t)P.ResX * idy + idx) * (uint32_t)P.RaysPerPixel;
         v3 rdir = normalize(worldFocalPos - cam);
 
-        traverse3<INSTR, true>(P, cam, rdir, rdir, laneStack(lds, P.stackDepth), t);
+        TRAVERSE<INSTR, true>(P, cam, rdir, rdir, laneStack(lds, P.stackDepth), t);
         rays = 1;
         const RisHit h = resolveRisHit(P, t, cam, rdir);
         const bool didHit = h.dst != INF();
@@ -304,7 +304,7 @@ __global__ __launch_bounds__(256, RT_MIN_WAVES) void k_ris_trace_rays(const KPar
                     rayColor = rayColor * lerp3(V3(material.color), V3(material.specularColor), isSpecularBounce ? 1.0f : 0.0f);
                     if (bounceCount != P.risMaxBounceCount) {
                         Trav t;
-                        traverse3<INSTR, true>(P, rpos, rdir, rdir, laneStack(lds, P.stackDepth), t);
+                        TRAVERSE<INSTR, true>(P, rpos, rdir, rdir, laneStack(lds, P.stackDepth), t);
                         rays++;
                         if (INSTR) {
                             pops += t.pops; bvc += (uint32_t)t.bvChecks; objv += t.objVisits; trii += t.triIters;

@@ -13,6 +13,7 @@
 #include <cstring>
 #include <map>
 #include <string>
+#include <algorithm>
 #include <vector>
 
 #include "../../include/rt_native.h"
@@ -22,7 +23,7 @@ using namespace rtn;
 namespace {
 
 enum ShaderKind { SH_RESTIR = 0, SH_RIS = 1, SH_PRECALC = 2, SH_POSTPROC = 3 };
-enum BufLayout { LAYOUT_AOS = 0, LAYOUT_RESERVOIR_PLANES = 1, LAYOUT_HIT_PLANES = 2 };
+enum BufLayout { LAYOUT_AOS = 0, LAYOUT_RESERVOIR_RECS = 1, LAYOUT_HIT_PLANES = 2 };
 // the kernels a dispatch is made of (one ABI dispatch may launch several)
 enum InternalKernel { IK_PRIMARY = 0, IK_CANDIDATES, IK_TEMPORAL, IK_SPATIAL, IK_TRANSFER, IK_TRACE_RAYS, IK_ACCUMULATE, IK_CALC_NORMALS,
                       IK_RIS_PRIMARY, IK_RIS_CANDIDATES, IK_RIS_TRACE_RAYS, IK_RIS_CALC_NORMALS, IK_COUNT };
@@ -126,21 +127,39 @@ Planes planesOf(rt_buffer b) {
     return p;
 }
 
-// Switches a 52-byte-stride buffer between the ABI's array-of-structures layout and the internal planes.
+Recs recsOf(rt_buffer b) {
+    Recs r;
+    r.q = (float4*)b->dev;
+    r.count = b->count;
+    return r;
+}
+// Device bytes of a buffer in a given layout: reservoir records are padded from 52 to 64 bytes.
+size_t layoutBytes(rt_buffer b, int layout) { return layout == LAYOUT_RESERVOIR_RECS ? (size_t)b->count * 64 : b->bytes; }
+
+// Enqueues the conversion of a 52-byte-stride buffer's contents into the ABI layout at `dst`.
+void launchToAos(rt_buffer b, void* dst) {
+    const int blocks = (int)((b->count + 255) / 256);
+    if (b->layout == LAYOUT_RESERVOIR_RECS) hipLaunchKernelGGL(k_recs_to_aos, dim3(blocks), dim3(256), 0, b->ctx->stream, recsOf(b), (float*)dst);
+    else hipLaunchKernelGGL(k_planes_to_aos, dim3(blocks), dim3(256), 0, b->ctx->stream, planesOf(b), (float*)dst);
+}
+
+// Switches a 52-byte-stride buffer between the ABI's array-of-structures layout and an internal one.
 int convertLayout(rt_buffer b, int target) {
     if (b->layout == target) return RT_OK;
     rt_ctx ctx = b->ctx;
     if (b->stride != 52) return fail(ctx, RT_ERR_INVALID_ARG, "buffer stride %d cannot hold a 52-byte per-pixel record", b->stride);
     if (b->layout != LAYOUT_AOS && target != LAYOUT_AOS) return fail(ctx, RT_ERR_INVALID_ARG, "buffer is bound as two different record types");
     void* tmp = nullptr;
-    HIP_TRY(ctx, hipMalloc(&tmp, b->bytes));
+    HIP_TRY(ctx, hipMalloc(&tmp, layoutBytes(b, target)));
     int blocks = (int)((b->count + 255) / 256);
     rt_buffer_s shadow = *b;
     shadow.dev = tmp;
     if (target == LAYOUT_AOS) {
-        hipLaunchKernelGGL(k_planes_to_aos, dim3(blocks), dim3(256), 0, ctx->stream, planesOf(b), (float*)tmp, b->layout == LAYOUT_RESERVOIR_PLANES ? 0 : 1);
+        launchToAos(b, tmp);
+    } else if (target == LAYOUT_RESERVOIR_RECS) {
+        hipLaunchKernelGGL(k_aos_to_recs, dim3(blocks), dim3(256), 0, ctx->stream, (const float*)b->dev, recsOf(&shadow));
     } else {
-        hipLaunchKernelGGL(k_aos_to_planes, dim3(blocks), dim3(256), 0, ctx->stream, (const float*)b->dev, planesOf(&shadow), target == LAYOUT_RESERVOIR_PLANES ? 0 : 1);
+        hipLaunchKernelGGL(k_aos_to_planes, dim3(blocks), dim3(256), 0, ctx->stream, (const float*)b->dev, planesOf(&shadow));
     }
     HIP_TRY(ctx, hipGetLastError());
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
@@ -334,6 +353,14 @@ int needPlanes(rt_shader sh, int kernel, const char* name, int layout, Planes& o
     out = planesOf(b);
     return RT_OK;
 }
+int needRecs(rt_shader sh, int kernel, const char* name, Recs& out) {
+    rt_buffer b = boundBuffer(sh, kernel, name);
+    if (!b) return fail(sh->ctx, RT_ERR_UNBOUND, "kernel %d: buffer '%s' is not bound", kernel, name);
+    int rc = convertLayout(b, LAYOUT_RESERVOIR_RECS);
+    if (rc) return rc;
+    out = recsOf(b);
+    return RT_OK;
+}
 int needTex(rt_shader sh, int kernel, const char* name, bool r32, int resX, int resY, Tex& out) {
     rt_texture t = boundTexture(sh, kernel, name);
     if (!t) return fail(sh->ctx, RT_ERR_UNBOUND, "kernel %d: texture '%s' is not bound", kernel, name);
@@ -408,6 +435,33 @@ std::vector<uint32_t> buildBlockMap(unsigned bx, unsigned by, int mode) {
     } else {
         const unsigned RW = 4, RH = 4;  // region = 4x4 blocks = 64x64 pixels
         unsigned rx = (bx + RW - 1) / RW, ry = (by + RH - 1) / RH, region = 0;
+        // EXPERIMENT: per-block costs from a file; regions dealt to the XCDs in order of descending cost
+        std::vector<uint32_t> cost;
+        if (const char* f = getenv("RT_BLOCK_COST_FILE")) {
+            FILE* fp = fopen(f, "rb");
+            if (fp) { cost.resize((size_t)bx * by); if (fread(cost.data(), 4, cost.size(), fp) != cost.size()) cost.clear(); fclose(fp); }
+        }
+        if (!cost.empty()) {
+            struct R { uint64_t c; unsigned i, j; };
+            std::vector<R> regs;
+            for (unsigned j = 0; j < ry; j++)
+                for (unsigned i = 0; i < rx; i++) {
+                    uint64_t c = 0;
+                    for (unsigned y = j * RH; y < (j + 1) * RH && y < by; y++)
+                        for (unsigned x = i * RW; x < (i + 1) * RW && x < bx; x++) c += cost[(size_t)y * bx + x];
+                    regs.push_back({c, i, j});
+                }
+            std::stable_sort(regs.begin(), regs.end(), [](const R& a, const R& b) { return a.c > b.c; });
+            const int blockSort = getenv("RT_BLOCK_SORT") ? atoi(getenv("RT_BLOCK_SORT")) : 0;
+            for (size_t k = 0; k < regs.size(); k++) {
+                std::vector<uint32_t>& l = lists[k % 8];
+                for (unsigned y = regs[k].j * RH; y < (regs[k].j + 1) * RH && y < by; y++)
+                    for (unsigned x = regs[k].i * RW; x < (regs[k].i + 1) * RW && x < bx; x++) l.push_back(y << 16 | x);
+            }
+            if (blockSort)
+                for (auto& l : lists)
+                    std::stable_sort(l.begin(), l.end(), [&](uint32_t a, uint32_t b) { return cost[(size_t)(a >> 16) * bx + (a & 0xffff)] > cost[(size_t)(b >> 16) * bx + (b & 0xffff)]; });
+        } else
         for (unsigned j = 0; j < ry; j++)
             for (unsigned i = 0; i < rx; i++, region++) {
                 // shift the cyclic assignment by row so vertically adjacent regions go to different XCDs too
@@ -511,7 +565,7 @@ int dispatchReSTIR(rt_shader sh, int kernel, int gx, int gy) {
     if (rc) return rc;
     const int X = P.ResX, Y = P.ResY;
     const int64_t npx = (int64_t)X * Y;
-    auto checkCount = [&](const Planes& pl, const char* name) -> int {
+    auto checkCount = [&](const auto& pl, const char* name) -> int {
         if (pl.count < npx) return fail(ctx, RT_ERR_INVALID_ARG, "buffer '%s' holds %lld records, Resolution needs %lld", name, (long long)pl.count, (long long)npx);
         return RT_OK;
     };
@@ -539,7 +593,7 @@ int dispatchReSTIR(rt_shader sh, int kernel, int gx, int gy) {
             if (lights->stride != 80) return fail(ctx, RT_ERR_INVALID_ARG, "LightObjects stride must be 80");
             P.lights = (const rt_light_object*)lights->dev; P.nLights = lights->count;
             if ((rc = needPlanes(sh, kernel, "HitInfos", LAYOUT_HIT_PLANES, P.hit)) || (rc = checkCount(P.hit, "HitInfos"))) return rc;
-            if ((rc = needPlanes(sh, kernel, "Candidates", LAYOUT_RESERVOIR_PLANES, P.cand)) || (rc = checkCount(P.cand, "Candidates"))) return rc;
+            if ((rc = needRecs(sh, kernel, "Candidates", P.cand)) || (rc = checkCount(P.cand, "Candidates"))) return rc;
             if ((rc = needTex(sh, kernel, "DebugOverlay", false, X, Y, P.debugOverlay))) return rc;
             if ((rc = needTex(sh, kernel, "DepthBuffer", true, X, Y, P.depth))) return rc;
             if ((rc = needTex(sh, kernel, "NormalsBuffer", false, X, Y, P.normals))) return rc;
@@ -561,24 +615,24 @@ int dispatchReSTIR(rt_shader sh, int kernel, int gx, int gy) {
             break;
         }
         case 1: {  // SpatialReusePass
-            if ((rc = needPlanes(sh, kernel, "Candidates", LAYOUT_RESERVOIR_PLANES, P.cand)) || (rc = checkCount(P.cand, "Candidates"))) return rc;
-            if ((rc = needPlanes(sh, kernel, "CandidatesB", LAYOUT_RESERVOIR_PLANES, P.candB)) || (rc = checkCount(P.candB, "CandidatesB"))) return rc;
+            if ((rc = needRecs(sh, kernel, "Candidates", P.cand)) || (rc = checkCount(P.cand, "Candidates"))) return rc;
+            if ((rc = needRecs(sh, kernel, "CandidatesB", P.candB)) || (rc = checkCount(P.candB, "CandidatesB"))) return rc;
             if ((rc = needTex(sh, kernel, "DepthBuffer", true, X, Y, P.depth))) return rc;
             if (!blocks) break;
             { LaunchScope ls(ctx, IK_SPATIAL, &P); hipLaunchKernelGGL(k_spatial, dim3(blocks), dim3(256), 0, ctx->stream, P); }
             break;
         }
         case 2: {  // TransferToOriginal
-            if ((rc = needPlanes(sh, kernel, "Candidates", LAYOUT_RESERVOIR_PLANES, P.cand)) || (rc = checkCount(P.cand, "Candidates"))) return rc;
-            if ((rc = needPlanes(sh, kernel, "CandidatesB", LAYOUT_RESERVOIR_PLANES, P.candB)) || (rc = checkCount(P.candB, "CandidatesB"))) return rc;
+            if ((rc = needRecs(sh, kernel, "Candidates", P.cand)) || (rc = checkCount(P.cand, "Candidates"))) return rc;
+            if ((rc = needRecs(sh, kernel, "CandidatesB", P.candB)) || (rc = checkCount(P.candB, "CandidatesB"))) return rc;
             if ((rc = needTex(sh, kernel, "DepthBuffer", true, X, Y, P.depth))) return rc;
             if (!blocks) break;
             { LaunchScope ls(ctx, IK_TRANSFER, &P); hipLaunchKernelGGL(k_transfer, dim3(blocks), dim3(256), 0, ctx->stream, P); }
             break;
         }
         case 3: {  // TemporalReuse
-            if ((rc = needPlanes(sh, kernel, "Candidates", LAYOUT_RESERVOIR_PLANES, P.cand)) || (rc = checkCount(P.cand, "Candidates"))) return rc;
-            if ((rc = needPlanes(sh, kernel, "TemporalFrameBuffer", LAYOUT_RESERVOIR_PLANES, P.temporal)) || (rc = checkCount(P.temporal, "TemporalFrameBuffer"))) return rc;
+            if ((rc = needRecs(sh, kernel, "Candidates", P.cand)) || (rc = checkCount(P.cand, "Candidates"))) return rc;
+            if ((rc = needRecs(sh, kernel, "TemporalFrameBuffer", P.temporal)) || (rc = checkCount(P.temporal, "TemporalFrameBuffer"))) return rc;
             if ((rc = needTex(sh, kernel, "DepthBuffer", true, X, Y, P.depth))) return rc;
             if ((rc = needTex(sh, kernel, "RayHitPointsA", false, X, Y, P.hitA))) return rc;
             if ((rc = needTex(sh, kernel, "RayHitPointsB", false, X, Y, P.hitB))) return rc;
@@ -589,8 +643,8 @@ int dispatchReSTIR(rt_shader sh, int kernel, int gx, int gy) {
         case 4: {  // TraceRays
             if ((rc = prepareScene(sh, kernel, P))) return rc;
             if ((rc = needPlanes(sh, kernel, "HitInfos", LAYOUT_HIT_PLANES, P.hit)) || (rc = checkCount(P.hit, "HitInfos"))) return rc;
-            if ((rc = needPlanes(sh, kernel, "Candidates", LAYOUT_RESERVOIR_PLANES, P.cand)) || (rc = checkCount(P.cand, "Candidates"))) return rc;
-            if ((rc = needPlanes(sh, kernel, "TemporalFrameBuffer", LAYOUT_RESERVOIR_PLANES, P.temporal)) || (rc = checkCount(P.temporal, "TemporalFrameBuffer"))) return rc;
+            if ((rc = needRecs(sh, kernel, "Candidates", P.cand)) || (rc = checkCount(P.cand, "Candidates"))) return rc;
+            if ((rc = needRecs(sh, kernel, "TemporalFrameBuffer", P.temporal)) || (rc = checkCount(P.temporal, "TemporalFrameBuffer"))) return rc;
             if ((rc = needTex(sh, kernel, "Result", false, X, Y, P.result))) return rc;
             optionalTex(sh, kernel, "TextureAtlas", P.atlas);
             optionalTex(sh, kernel, "EnvironmentMap", P.env);
@@ -947,8 +1001,7 @@ int rt_buffer_get_data(rt_buffer b, void* dst, size_t bytes) {
     }
     void* tmp = nullptr;
     HIP_TRY(ctx, hipMalloc(&tmp, b->bytes));
-    hipLaunchKernelGGL(k_planes_to_aos, dim3((unsigned)((b->count + 255) / 256)), dim3(256), 0, ctx->stream, planesOf(b), (float*)tmp,
-                       b->layout == LAYOUT_RESERVOIR_PLANES ? 0 : 1);
+    launchToAos(b, tmp);
     hipError_t e = hipGetLastError();
     if (e == hipSuccess) e = hipMemcpyAsync(dst, tmp, bytes, hipMemcpyDeviceToHost, ctx->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
@@ -1049,6 +1102,9 @@ int rt_buffer_map_rows(rt_buffer b, int width, int row0, int row1, rt_segment ou
     char* base = (char*)b->dev;
     if (b->layout == LAYOUT_AOS) {
         out[0].ptr = base + first * b->stride; out[0].bytes = n * b->stride;
+        *count = 1;
+    } else if (b->layout == LAYOUT_RESERVOIR_RECS) {
+        out[0].ptr = base + first * 64; out[0].bytes = n * 64;
         *count = 1;
     } else {
         for (int k = 0; k < 3; k++) { out[k].ptr = base + (size_t)b->count * 16 * k + first * 16; out[k].bytes = n * 16; }

@@ -22,6 +22,24 @@ __global__ __launch_bounds__(256) void k(const float4* rec, uint32_t n, int step
         if (MODE == 0) { const float4* r = rec + (size_t)idx * 4; a = r[0]; b = r[1]; c = r[2]; d = r[3]; }
         else if (MODE == 1) { const float4* r = rec + (size_t)idx * 4; a = r[0]; b = a; c = a; d = a; }           // one 16-byte load
         else if (MODE == 2) { const float4* r = rec + (size_t)idx * 4; a = r[0]; b = r[1]; c = a; d = b; }        // two loads
+        else if (MODE == 4 || MODE == 5) {
+            // cooperative: instruction k fetches the records of lanes 16k..16k+15, four adjacent lanes reading the four
+            // quarters of one record (coalesced 64-byte runs), then the wave transposes through LDS
+            const int STR = MODE == 5 ? 5 : 4;   // record stride in float4 (5: padded against bank conflicts)
+            float4* my = cache + (threadIdx.x >> 6) * (64 * 5);
+            #pragma unroll
+            for (int q = 0; q < 4; q++) {
+                uint32_t j = __shfl(idx, q * 16 + (lane >> 2));
+                float4 piece = rec[(size_t)j * 4 + (lane & 3)];
+                my[(q * 16 + (lane >> 2)) * STR + (lane & 3)] = piece;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            a = my[lane * STR]; b = my[lane * STR + 1]; c = my[lane * STR + 2]; d = my[lane * STR + 3];
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        }
         else { const float4* r = cache + (size_t)(idx & 1023) * 4; a = r[0]; b = r[1]; c = r[2]; d = r[3]; }      // LDS
         acc += a.x + b.y + c.z + d.w;
         idx = (__float_as_uint(a.x) ^ __float_as_uint(d.w) ^ (idx * 747796405u + lane)) & (n - 1);   // dependent next index (n is a power of two)
@@ -40,16 +58,18 @@ int main(int argc, char** argv) {
     CHECK(hipMalloc(&out, 4096 * 256 * 4));
     hipEvent_t e0, e1;
     CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
-    const char* names[4] = {"4x16B global", "1x16B global", "2x16B global", "4x16B LDS"};
+    const char* names[6] = {"4x16B global", "1x16B global", "2x16B global", "4x16B LDS", "coop quads", "coop padded"};
     for (int coherent = 0; coherent < 1; coherent++)
-        for (int mode = 0; mode < 4; mode++)
+        for (int mode = 0; mode < 6; mode++)
             for (int blocks : {256, 512, 1024, 2048}) {
-                size_t lds = mode == 3 ? 65536 : 0;
+                size_t lds = mode == 3 ? 65536 : (mode >= 4 ? 4 * 64 * 5 * 16 : 0);
                 auto launch = [&]() {
                     if (mode == 0) hipLaunchKernelGGL(k<0>, dim3(blocks), dim3(256), lds, 0, rec, n, steps, out, coherent);
                     if (mode == 1) hipLaunchKernelGGL(k<1>, dim3(blocks), dim3(256), lds, 0, rec, n, steps, out, coherent);
                     if (mode == 2) hipLaunchKernelGGL(k<2>, dim3(blocks), dim3(256), lds, 0, rec, n, steps, out, coherent);
                     if (mode == 3) hipLaunchKernelGGL(k<3>, dim3(blocks), dim3(256), lds, 0, rec, n, steps, out, coherent);
+                    if (mode == 4) hipLaunchKernelGGL(k<4>, dim3(blocks), dim3(256), lds, 0, rec, n, steps, out, coherent);
+                    if (mode == 5) hipLaunchKernelGGL(k<5>, dim3(blocks), dim3(256), lds, 0, rec, n, steps, out, coherent);
                 };
                 launch();
                 CHECK(hipDeviceSynchronize());
