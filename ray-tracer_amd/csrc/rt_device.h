@@ -33,10 +33,12 @@ constexpr int ENTRY_INLINE_MAX_START = (1 << 26) - 1;
 //   q0 = v0.xyz, N.x   q1 = edgeAB.xyz, N.y   q2 = edgeAC.xyz, N.z   q3 = localNormal.xyz, 0
 // with N = cross(edgeAB, edgeAC), computed with the same fp32 operations the intersection routine would use.
 
-// The per-pixel hit records are kept as planes of 16-byte elements (structure of arrays): the 52-byte record of
-// `count` pixels is stored as three float4 planes followed by one float plane, in the same 52*count bytes.  Every
-// access is then one coalesced 16-byte-per-lane load or store (a hit record is only ever read at the thread's own pixel).
+// Per-pixel records that are only ever accessed at the thread's own pixel (HitInfos, TemporalFrameBuffer) are kept
+// as planes of 16-byte elements (structure of arrays): the 52-byte record of `count` pixels is stored as three float4
+// planes followed by one float plane, in the same 52*count bytes.  Every access is then one coalesced
+// 16-byte-per-lane load or store.
 //   hit info : p0 = hitPoint.xyz, dst       p1 = normal.xyz, materialIndex  p2 = incomingDir.xyz, uv.x       p3 = uv.y
+//   reservoir: p0 = dir.xyz, chosenWeight   p1 = hitPoint.xyz, totWeights   p2 = normal.xyz, totCandidates   p3 = brdf
 struct Planes {
     float4* p0;
     float4* p1;
@@ -44,8 +46,8 @@ struct Planes {
     float* p3;
     int64_t count;
 };
-// Reservoirs are also GATHERED, from random neighbouring pixels (SpatialReusePass reads nine per pixel and pass): each
-// is one aligned 64-byte record, so a gathered reservoir costs one cache line instead of four.
+// Candidates and CandidatesB are also GATHERED, from random neighbouring pixels (SpatialReusePass reads nine per pixel
+// and pass): there a reservoir is one aligned 64-byte record, so a gathered one costs one cache line instead of four.
 //   q0 = dir.xyz, chosenWeight   q1 = hitPoint.xyz, totWeights   q2 = normal.xyz, totCandidates   q3 = brdf, 0, 0, 0
 struct Recs {
     float4* q;  // 4 per pixel
@@ -75,8 +77,8 @@ struct KParams {
     int stackDepth;  // dwords of LDS stack per lane
     Tex atlas, env;
     // per-pixel state
-    Planes hit;
-    Recs cand, candB, temporal;
+    Planes hit, temporal;
+    Recs cand, candB;
     Tex result, accumulated, debugOverlay, depth, normals, hitA, hitB;
     // constants
     uint32_t MaxBVHDepth;

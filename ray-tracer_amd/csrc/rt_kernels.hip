@@ -9,7 +9,8 @@
 //     entries) and one aligned 64-byte record per triangle; the per-lane traversal stack lives in LDS,
 //     lane-interleaved (conflict-free), one dword per entry, shared by the scene level and the mesh level;
 //   * the reference's InitialTrace is split into a primary-ray kernel and a candidate + shadow-ray kernel;
-//   * per-pixel records are planes of float4 (16-byte coalesced accesses).
+//   * per-pixel records that are only read at the thread's own pixel are planes of float4 (16-byte coalesced
+//     accesses); the reservoirs that SpatialReusePass gathers from neighbouring pixels are aligned 64-byte records.
 // Arithmetic follows the fp32 conventions documented in include/rt_detmath.h: no contraction
 // (-ffp-contract=off), IEEE divide/sqrt, fixed summation order, so results are bit-identical to the CPU oracle.
 #include "rt_device.h"
@@ -30,14 +31,7 @@ constexpr int WAVES_PER_BLOCK = 4;
 #ifndef RT_MIN_WAVES
 #define RT_MIN_WAVES 1
 #endif
-#ifndef RT_TRAV
-#define RT_TRAV 3
-#endif
-#if RT_TRAV == 4
-#define TRAVERSE traverse4
-#else
 #define TRAVERSE traverse3
-#endif
 
 struct v2 { float x, y; };
 struct v3 { float x, y, z; };
@@ -424,107 +418,6 @@ DEV void traverse3(const KParams& P, const v3 wpos, const v3 wdir, const v3 winv
     while (__builtin_amdgcn_ballot_w64(alive) != 0) travTrip<INSTR, RIS>(P, s, t, stk, alive);
 }
 
-// ---- Variant with ONE 64-byte fetch per trip: a lane at an internal node fetches its wide record, a lane inside a
-// leaf fetches its next baked triangle, through the same four loads; only the arithmetic afterwards differs per lane.
-// A trip then costs one memory latency whatever mix of lanes the wave holds, and no lane waits for a phase.
-struct TravState4 : TravState { int triCur, triEnd; };
-
-// Turns a held leaf entry into a run of triangles (inside an object) or of scene objects (scene level).
-template <bool INSTR>
-DEV void travDecodeLeaf(const KParams& P, TravState4& s, Trav& t, const uint32_t* stk) {
-    const uint32_t e = s.e;
-    int start, count;
-    if (e & ENTRY_LEAF) {
-        start = (int)(e & (uint32_t)ENTRY_INLINE_MAX_START);
-        count = (int)((e >> 26) & 31u);
-        if (INSTR) { t.hash = (t.hash ^ (uint32_t)start) * 16777619u; t.hash = (t.hash ^ (uint32_t)count) * 16777619u; }
-    } else {
-        const rt_bv* bv = &P.BVs[e & ENTRY_INDEX_MASK];
-        int a = bv->indexA, b = bv->indexB;
-        if (INSTR) { t.hash = (t.hash ^ (uint32_t)a) * 16777619u; t.hash = (t.hash ^ (uint32_t)b) * 16777619u; }
-        start = a < 0 ? -a : a;
-        count = b < 0 ? -b : b;
-    }
-    if (INSTR) t.iters++;
-    if (s.objBase < 0) {  // scene-level leaf: its objects are entered one by one by the service step
-        s.objCur = start;
-        s.objEnd = start + count;
-        s.e = ENTRY_NONE;
-    } else if (count > 0) {
-        s.triCur = start;
-        s.triEnd = start + count;
-        s.e = ENTRY_NONE;
-    } else {
-        travPop<INSTR>(P, s, t, stk);
-    }
-}
-
-template <bool INSTR, bool RIS>
-DEV void travTrip4(const KParams& P, TravState4& s, Trav& t, uint32_t* stk, bool& alive) {
-    if (alive && s.e != ENTRY_NONE && (s.e & LEAF_BITS) != 0) travDecodeLeaf<INSTR>(P, s, t, stk);
-    if (alive && s.e == ENTRY_NONE && s.triCur >= s.triEnd) alive = travService<INSTR, RIS>(P, s, t, stk);
-    if (alive && s.e != ENTRY_NONE && (s.e & LEAF_BITS) != 0) travDecodeLeaf<INSTR>(P, s, t, stk);
-    const bool isTri = alive && s.e == ENTRY_NONE && s.triCur < s.triEnd;
-    const bool isInt = alive && s.e != ENTRY_NONE && (s.e & LEAF_BITS) == 0;
-    if (!(isTri || isInt)) return;
-    const float4* rec = isInt ? P.wide + (int64_t)s.e * 4 : P.btri + (int64_t)s.triCur * 4;
-    const float4 q0 = rec[0], q1 = rec[1], q2 = rec[2], q3 = rec[3];
-    if (isInt) {  // RS:195-214
-        const uint32_t e = s.e;
-        if (INSTR) { t.iters++; t.hash = (t.hash ^ (0x80000000u | e)) * 16777619u; }
-        const float dstA = RIS ? RayBVIntersectDiv(s.rpos, s.rdir, V3(q0.x, q0.y, q0.z), V3(q0.w, q1.x, q1.y))
-                               : RayBVIntersect(s.rpos, s.rinv, V3(q0.x, q0.y, q0.z), V3(q0.w, q1.x, q1.y));
-        const float dstB = RIS ? RayBVIntersectDiv(s.rpos, s.rdir, V3(q1.z, q1.w, q2.x), V3(q2.y, q2.z, q2.w))
-                               : RayBVIntersect(s.rpos, s.rinv, V3(q1.z, q1.w, q2.x), V3(q2.y, q2.z, q2.w));
-        t.bvChecks += 2;
-        const uint32_t eA = __float_as_uint(q3.x), eB = __float_as_uint(q3.y);
-        const bool aFirst = dstA < dstB;  // the nearer child is visited first
-        const uint32_t eNear = aFirst ? eA : eB, eFar = aFirst ? eB : eA;
-        const bool nearHit = (aFirst ? dstA : dstB) < s.best, farHit = (aFirst ? dstB : dstA) < s.best;
-        if (nearHit) {
-            if (farHit) { if (s.sp < P.stackDepth) stk[s.sp * 64] = eFar; s.sp++; }
-            s.e = eNear;
-            if (INSTR) t.pops++;
-        } else if (farHit) {
-            s.e = eFar;
-            if (INSTR) t.pops++;
-        } else {
-            travPop<INSTR>(P, s, t, stk);
-        }
-    } else {      // one triangle of the leaf's run, RS:179-193
-        const int triIndex = s.triCur;
-        if (INSTR) t.triIters++;
-        const bool facing = RIS || dot(V3(q3.x, q3.y, q3.z), s.rdir) <= 0;
-        if (facing) {
-            // RayTriangleIntersect, RS:119-146
-            v3 edgeAB = V3(q1.x, q1.y, q1.z), edgeAC = V3(q2.x, q2.y, q2.z);
-            v3 normalVector = V3(q0.w, q1.w, q2.w);
-            v3 ao = s.rpos - V3(q0.x, q0.y, q0.z);
-            v3 dao = cross(ao, s.rdir);
-            float determinant = -dot(s.rdir, normalVector);
-            float invDet = 1 / determinant;
-            float dst = dot(ao, normalVector) * invDet;
-            float u = dot(edgeAC, dao) * invDet;
-            float v = -dot(edgeAB, dao) * invDet;
-            float w = 1 - u - v;
-            bool didHit = determinant >= 1E-8f && dst >= 0 && u >= 0 && v >= 0 && w >= 0;
-            t.triChecks++;
-            if (didHit && dst < s.best) { s.best = dst; s.localU = u; s.localV = v; s.localTri = triIndex; }
-        }
-        s.triCur = triIndex + 1;
-        if (s.triCur >= s.triEnd) travPop<INSTR>(P, s, t, stk);
-    }
-}
-
-template <bool INSTR, bool RIS = false>
-DEV void traverse4(const KParams& P, const v3 wpos, const v3 wdir, const v3 winv, uint32_t* stk, Trav& t) {
-    TravState4 s;
-    travBegin<INSTR>(P, s, t, wpos, wdir, winv);
-    s.triCur = 0; s.triEnd = 0;
-    bool alive = true;
-    while (__builtin_amdgcn_ballot_w64(alive) != 0) travTrip4<INSTR, RIS>(P, s, t, stk, alive);
-}
-
 // Shading data of a traversal result, as TraverseSceneBVH leaves it in hitInfo (RS:248-258).
 struct HitInfo { float dst; v3 hitPoint; v2 uv; v3 normal; v3 incomingDir; int materialIndex; };
 DEV HitInfo resolveHit(const KParams& P, const Trav& t, v3 wpos, v3 wdir) {
@@ -616,6 +509,16 @@ DEV Reservoir unpackReservoir(float4 a, float4 b, float4 c, float4 d) {
     r.normal = V3(c.x, c.y, c.z); r.totCandidates = c.w;
     r.brdf = d.x;
     return r;
+}
+DEV void storeReservoir(const Planes& pl, int64_t i, const Reservoir& r) {
+    pl.p0[i] = make_float4(r.dir.x, r.dir.y, r.dir.z, r.chosenWeight);
+    pl.p1[i] = make_float4(r.hitPoint.x, r.hitPoint.y, r.hitPoint.z, r.totWeights);
+    pl.p2[i] = make_float4(r.normal.x, r.normal.y, r.normal.z, r.totCandidates);
+    pl.p3[i] = r.brdf;
+}
+DEV Reservoir loadReservoir(const Planes& pl, int64_t i) {
+    if (i < 0 || i >= pl.count) return emptyReservoir();
+    return unpackReservoir(pl.p0[i], pl.p1[i], pl.p2[i], make_float4(pl.p3[i], 0.0f, 0.0f, 0.0f));
 }
 // index beyond the buffer -> zero reservoir
 DEV Reservoir loadReservoir(const Recs& rc, int64_t i) {
@@ -1010,8 +913,8 @@ __global__ __launch_bounds__(256, 5) void k_trace_rays(const KParams P) {
                         v2 wb = GenerateCandidateWeight(P, sqr(hitInfo.dst), fmaxf_(dot(hitInfo.normal, rdir), 0),
                                                         incomingDir, rdir, hitInfo.normal, metallicity, roughness,
                                                         material.brightness);
-                        P.temporal.q[(int64_t)pixelIndex * 4].w = wb.x;      // chosenWeight
-                        P.temporal.q[(int64_t)pixelIndex * 4 + 3].x = wb.y;  // brdf
+                        P.temporal.p0[pixelIndex].w = wb.x;  // chosenWeight
+                        P.temporal.p3[pixelIndex] = wb.y;    // brdf
                     }
                 }
                 v3 col = matCol(P, material, hitInfo.uv);
@@ -1131,29 +1034,43 @@ __global__ void k_bake_tris(const rt_triangle* tris, int64_t nTris, const rt_ver
     out[i * 4 + 3] = make_float4(tri.localNormal.x, tri.localNormal.y, tri.localNormal.z, 0.0f);
 }
 
-// 52-byte ABI records <-> the internal layouts (see rt_device.h).
-// HitInfo: dst 0, hitPoint 1-3, uv 4-5, normal 6-8, incomingDir 9-11, materialIndex 12.
-__global__ void k_aos_to_planes(const float* aos, Planes pl) {
+// 52-byte ABI records <-> the internal layouts (see rt_device.h).  kind 0 = CandidateReservoir: dir 0-2, hitPoint 3-5,
+// normal 6-8, brdf 9, chosenWeight 10, totWeights 11, totCandidates 12; kind 1 = HitInfo: dst 0, hitPoint 1-3, uv 4-5,
+// normal 6-8, incomingDir 9-11, materialIndex 12.
+__global__ void k_aos_to_planes(const float* aos, Planes pl, int kind) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= pl.count) return;
     const float* r = aos + i * 13;
-    pl.p0[i] = make_float4(r[1], r[2], r[3], r[0]);
-    pl.p1[i] = make_float4(r[6], r[7], r[8], r[12]);
-    pl.p2[i] = make_float4(r[9], r[10], r[11], r[4]);
-    pl.p3[i] = r[5];
+    if (kind == 0) {
+        pl.p0[i] = make_float4(r[0], r[1], r[2], r[10]);
+        pl.p1[i] = make_float4(r[3], r[4], r[5], r[11]);
+        pl.p2[i] = make_float4(r[6], r[7], r[8], r[12]);
+        pl.p3[i] = r[9];
+    } else {
+        pl.p0[i] = make_float4(r[1], r[2], r[3], r[0]);
+        pl.p1[i] = make_float4(r[6], r[7], r[8], r[12]);
+        pl.p2[i] = make_float4(r[9], r[10], r[11], r[4]);
+        pl.p3[i] = r[5];
+    }
 }
-__global__ void k_planes_to_aos(Planes pl, float* aos) {
+__global__ void k_planes_to_aos(Planes pl, float* aos, int kind) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= pl.count) return;
     float* r = aos + i * 13;
     float4 a = pl.p0[i], b = pl.p1[i], c = pl.p2[i];
     float d = pl.p3[i];
-    r[1] = a.x; r[2] = a.y; r[3] = a.z; r[0] = a.w;
-    r[6] = b.x; r[7] = b.y; r[8] = b.z; r[12] = b.w;
-    r[9] = c.x; r[10] = c.y; r[11] = c.z; r[4] = c.w;
-    r[5] = d;
+    if (kind == 0) {
+        r[0] = a.x; r[1] = a.y; r[2] = a.z; r[10] = a.w;
+        r[3] = b.x; r[4] = b.y; r[5] = b.z; r[11] = b.w;
+        r[6] = c.x; r[7] = c.y; r[8] = c.z; r[12] = c.w;
+        r[9] = d;
+    } else {
+        r[1] = a.x; r[2] = a.y; r[3] = a.z; r[0] = a.w;
+        r[6] = b.x; r[7] = b.y; r[8] = b.z; r[12] = b.w;
+        r[9] = c.x; r[10] = c.y; r[11] = c.z; r[4] = c.w;
+        r[5] = d;
+    }
 }
-// CandidateReservoir: dir 0-2, hitPoint 3-5, normal 6-8, brdf 9, chosenWeight 10, totWeights 11, totCandidates 12.
 __global__ void k_aos_to_recs(const float* aos, Recs rc) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= rc.count) return;

@@ -23,7 +23,7 @@ using namespace rtn;
 namespace {
 
 enum ShaderKind { SH_RESTIR = 0, SH_RIS = 1, SH_PRECALC = 2, SH_POSTPROC = 3 };
-enum BufLayout { LAYOUT_AOS = 0, LAYOUT_RESERVOIR_RECS = 1, LAYOUT_HIT_PLANES = 2 };
+enum BufLayout { LAYOUT_AOS = 0, LAYOUT_RESERVOIR_RECS = 1, LAYOUT_HIT_PLANES = 2, LAYOUT_RESERVOIR_PLANES = 3 };
 // the kernels a dispatch is made of (one ABI dispatch may launch several)
 enum InternalKernel { IK_PRIMARY = 0, IK_CANDIDATES, IK_TEMPORAL, IK_SPATIAL, IK_TRANSFER, IK_TRACE_RAYS, IK_ACCUMULATE, IK_CALC_NORMALS,
                       IK_RIS_PRIMARY, IK_RIS_CANDIDATES, IK_RIS_TRACE_RAYS, IK_RIS_CALC_NORMALS, IK_COUNT };
@@ -140,7 +140,7 @@ size_t layoutBytes(rt_buffer b, int layout) { return layout == LAYOUT_RESERVOIR_
 void launchToAos(rt_buffer b, void* dst) {
     const int blocks = (int)((b->count + 255) / 256);
     if (b->layout == LAYOUT_RESERVOIR_RECS) hipLaunchKernelGGL(k_recs_to_aos, dim3(blocks), dim3(256), 0, b->ctx->stream, recsOf(b), (float*)dst);
-    else hipLaunchKernelGGL(k_planes_to_aos, dim3(blocks), dim3(256), 0, b->ctx->stream, planesOf(b), (float*)dst);
+    else hipLaunchKernelGGL(k_planes_to_aos, dim3(blocks), dim3(256), 0, b->ctx->stream, planesOf(b), (float*)dst, b->layout == LAYOUT_RESERVOIR_PLANES ? 0 : 1);
 }
 
 // Switches a 52-byte-stride buffer between the ABI's array-of-structures layout and an internal one.
@@ -159,7 +159,7 @@ int convertLayout(rt_buffer b, int target) {
     } else if (target == LAYOUT_RESERVOIR_RECS) {
         hipLaunchKernelGGL(k_aos_to_recs, dim3(blocks), dim3(256), 0, ctx->stream, (const float*)b->dev, recsOf(&shadow));
     } else {
-        hipLaunchKernelGGL(k_aos_to_planes, dim3(blocks), dim3(256), 0, ctx->stream, (const float*)b->dev, planesOf(&shadow));
+        hipLaunchKernelGGL(k_aos_to_planes, dim3(blocks), dim3(256), 0, ctx->stream, (const float*)b->dev, planesOf(&shadow), target == LAYOUT_RESERVOIR_PLANES ? 0 : 1);
     }
     HIP_TRY(ctx, hipGetLastError());
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
@@ -435,33 +435,6 @@ std::vector<uint32_t> buildBlockMap(unsigned bx, unsigned by, int mode) {
     } else {
         const unsigned RW = 4, RH = 4;  // region = 4x4 blocks = 64x64 pixels
         unsigned rx = (bx + RW - 1) / RW, ry = (by + RH - 1) / RH, region = 0;
-        // EXPERIMENT: per-block costs from a file; regions dealt to the XCDs in order of descending cost
-        std::vector<uint32_t> cost;
-        if (const char* f = getenv("RT_BLOCK_COST_FILE")) {
-            FILE* fp = fopen(f, "rb");
-            if (fp) { cost.resize((size_t)bx * by); if (fread(cost.data(), 4, cost.size(), fp) != cost.size()) cost.clear(); fclose(fp); }
-        }
-        if (!cost.empty()) {
-            struct R { uint64_t c; unsigned i, j; };
-            std::vector<R> regs;
-            for (unsigned j = 0; j < ry; j++)
-                for (unsigned i = 0; i < rx; i++) {
-                    uint64_t c = 0;
-                    for (unsigned y = j * RH; y < (j + 1) * RH && y < by; y++)
-                        for (unsigned x = i * RW; x < (i + 1) * RW && x < bx; x++) c += cost[(size_t)y * bx + x];
-                    regs.push_back({c, i, j});
-                }
-            std::stable_sort(regs.begin(), regs.end(), [](const R& a, const R& b) { return a.c > b.c; });
-            const int blockSort = getenv("RT_BLOCK_SORT") ? atoi(getenv("RT_BLOCK_SORT")) : 0;
-            for (size_t k = 0; k < regs.size(); k++) {
-                std::vector<uint32_t>& l = lists[k % 8];
-                for (unsigned y = regs[k].j * RH; y < (regs[k].j + 1) * RH && y < by; y++)
-                    for (unsigned x = regs[k].i * RW; x < (regs[k].i + 1) * RW && x < bx; x++) l.push_back(y << 16 | x);
-            }
-            if (blockSort)
-                for (auto& l : lists)
-                    std::stable_sort(l.begin(), l.end(), [&](uint32_t a, uint32_t b) { return cost[(size_t)(a >> 16) * bx + (a & 0xffff)] > cost[(size_t)(b >> 16) * bx + (b & 0xffff)]; });
-        } else
         for (unsigned j = 0; j < ry; j++)
             for (unsigned i = 0; i < rx; i++, region++) {
                 // shift the cyclic assignment by row so vertically adjacent regions go to different XCDs too
@@ -632,7 +605,7 @@ int dispatchReSTIR(rt_shader sh, int kernel, int gx, int gy) {
         }
         case 3: {  // TemporalReuse
             if ((rc = needRecs(sh, kernel, "Candidates", P.cand)) || (rc = checkCount(P.cand, "Candidates"))) return rc;
-            if ((rc = needRecs(sh, kernel, "TemporalFrameBuffer", P.temporal)) || (rc = checkCount(P.temporal, "TemporalFrameBuffer"))) return rc;
+            if ((rc = needPlanes(sh, kernel, "TemporalFrameBuffer", LAYOUT_RESERVOIR_PLANES, P.temporal)) || (rc = checkCount(P.temporal, "TemporalFrameBuffer"))) return rc;
             if ((rc = needTex(sh, kernel, "DepthBuffer", true, X, Y, P.depth))) return rc;
             if ((rc = needTex(sh, kernel, "RayHitPointsA", false, X, Y, P.hitA))) return rc;
             if ((rc = needTex(sh, kernel, "RayHitPointsB", false, X, Y, P.hitB))) return rc;
@@ -644,7 +617,7 @@ int dispatchReSTIR(rt_shader sh, int kernel, int gx, int gy) {
             if ((rc = prepareScene(sh, kernel, P))) return rc;
             if ((rc = needPlanes(sh, kernel, "HitInfos", LAYOUT_HIT_PLANES, P.hit)) || (rc = checkCount(P.hit, "HitInfos"))) return rc;
             if ((rc = needRecs(sh, kernel, "Candidates", P.cand)) || (rc = checkCount(P.cand, "Candidates"))) return rc;
-            if ((rc = needRecs(sh, kernel, "TemporalFrameBuffer", P.temporal)) || (rc = checkCount(P.temporal, "TemporalFrameBuffer"))) return rc;
+            if ((rc = needPlanes(sh, kernel, "TemporalFrameBuffer", LAYOUT_RESERVOIR_PLANES, P.temporal)) || (rc = checkCount(P.temporal, "TemporalFrameBuffer"))) return rc;
             if ((rc = needTex(sh, kernel, "Result", false, X, Y, P.result))) return rc;
             optionalTex(sh, kernel, "TextureAtlas", P.atlas);
             optionalTex(sh, kernel, "EnvironmentMap", P.env);
