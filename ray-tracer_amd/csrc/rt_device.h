@@ -111,6 +111,8 @@ struct KParams {
     // band + instrumentation
     int32_t row0, row1;
     const uint32_t* blockMap;  // launch block index -> (by << 16 | bx) of the 16x16-pixel block it renders, ~0u = none
+    uint32_t* blockCost;       // InitialTrace only, may be null: hit pixels per wave, [(by * blocksX + bx) * 4 + wave]
+    int blocksX;               // blocks per image row of this launch's grid
     unsigned long long* stats;  // sharded counters (rt_dispatch_stats order) or null
     int32_t statsLevel;         // 1: rays only, 2: everything
     uint32_t* records;          // 8 dwords per pixel (trace record) or null

@@ -203,6 +203,15 @@ DEV Pixel pixelOfThread(const KParams& P) {
     return p;
 }
 
+// Cost estimate of this wave's tile for the launches that follow the primary-ray kernel: its number of hit pixels.
+DEV void writeTileCost(const KParams& P, bool hit) {
+    if (!P.blockCost) return;
+    const unsigned long long hitMask = __builtin_amdgcn_ballot_w64(hit);
+    const uint32_t m = P.blockMap[blockIdx.x];
+    if ((threadIdx.x & 63) == 0 && m != 0xffffffffu)
+        P.blockCost[((size_t)(m >> 16) * P.blocksX + (m & 0xffffu)) * 4 + (threadIdx.x >> 6)] = (uint32_t)__builtin_popcountll(hitMask);
+}
+
 // ---------------- BVH traversal ----------------
 struct Trav {
     float dst;        // closest hit distance along the world ray, INF on a miss
@@ -554,6 +563,7 @@ __global__ __launch_bounds__(256, RT_MIN_WAVES) void k_primary(const KParams P) 
     const Pixel px = pixelOfThread(P);
     uint32_t rays = 0;
     Trav t;
+    t.dst = INF();
     if (INSTR) { t.pops = t.objVisits = t.triIters = t.iters = 0; t.triChecks = t.bvChecks = 0; }
     unsigned long long tStart = 0;
     if (INSTR && P.waveProfile) tStart = wall_clock64();
@@ -593,6 +603,7 @@ __global__ __launch_bounds__(256, RT_MIN_WAVES) void k_primary(const KParams P) 
             r[5] = 0; r[6] = 0xffffffffu; r[7] = 0;
         }
     }
+    writeTileCost(P, px.active && t.dst != INF());
     if (INSTR && P.waveProfile && P.waveProfileKernel == 0) writeWaveProfile(P, tStart, px.active ? t.iters : 0);
     if (P.stats) {
         waveAdd(P.stats + ST_RAYS, rays);
@@ -1092,6 +1103,51 @@ __global__ void k_recs_to_aos(Recs rc, float* aos) {
     r[6] = c.x; r[7] = c.y; r[8] = c.z; r[12] = c.w;
     r[9] = d.x;
 }
+// Rebuilds the workgroup -> block table with the heaviest 64x64-pixel regions first (longest-processing-time-first:
+// the launches that follow end with light regions instead of with a few heavy waves on an otherwise idle chip).
+// Regions are ranked by their hit pixels in steps of 64 (a counting sort; the order inside a step is whatever the
+// atomics give: any permutation renders the same image) and dealt to the 8 XCDs in that order; every XCD still walks
+// whole regions.  One workgroup; `dyn` has ceil(regions / 8) * 128 entries.
+constexpr int ORDER_MAX_REGIONS = 4096;
+__global__ __launch_bounds__(1024) void k_order_blocks(const uint32_t* costW, int BX, int BY, uint32_t* dyn, unsigned nDyn) {
+    __shared__ uint32_t hist[66], order[ORDER_MAX_REGIONS];
+    __shared__ uint8_t bucketOf[ORDER_MAX_REGIONS];
+    const int RX = (BX + 3) / 4, RY = (BY + 3) / 4, R = RX * RY;
+    const int t = (int)threadIdx.x;
+    if (t < 66) hist[t] = 0;
+    __syncthreads();
+    for (int r = t; r < R; r += 1024) {
+        const int ri = r % RX, rj = r / RX;
+        uint32_t c = 0;
+        for (int y = rj * 4; y < rj * 4 + 4 && y < BY; y++)
+            for (int x = ri * 4; x < ri * 4 + 4 && x < BX; x++) {
+                const uint32_t* w = costW + ((size_t)y * BX + x) * 4;
+                c += w[0] + w[1] + w[2] + w[3];
+            }
+        const uint32_t step = c / 64 > 64 ? 64 : c / 64;
+        bucketOf[r] = (uint8_t)(64 - step);  // bucket 0 = heaviest
+        atomicAdd(&hist[64 - step], 1u);
+    }
+    __syncthreads();
+    if (t == 0) {
+        uint32_t run = 0;
+        for (int b = 0; b < 65; b++) { const uint32_t n = hist[b]; hist[b] = run; run += n; }
+    }
+    __syncthreads();
+    for (int r = t; r < R; r += 1024) order[atomicAdd(&hist[bucketOf[r]], 1u)] = (uint32_t)r;
+    __syncthreads();
+    for (unsigned m = (unsigned)t; m < nDyn; m += 1024) {
+        const unsigned xcd = m % 8, j = m / 8, ord = (j / 16) * 8 + xcd, k = j % 16;
+        uint32_t entry = 0xffffffffu;
+        if ((int)ord < R) {
+            const uint32_t r = order[ord];
+            const int x = (int)(r % RX) * 4 + (int)(k % 4), y = (int)(r / RX) * 4 + (int)(k / 4);
+            if (x < BX && y < BY) entry = (uint32_t)y << 16 | (uint32_t)x;
+        }
+        dyn[m] = entry;
+    }
+}
+
 __global__ void k_rgba8_to_f32(const uint8_t* src, float4* dst, int64_t n) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;

@@ -81,6 +81,7 @@ __global__ __launch_bounds__(256, RT_MIN_WAVES) void k_ris_primary(const KParams
     const Pixel px = pixelOfThread(P);
     uint32_t rays = 0;
     Trav t;
+    t.dst = INF();
     if (INSTR) { t.pops = t.objVisits = t.triIters = t.iters = 0; t.triChecks = t.bvChecks = 0; }
     if (px.active) {
         const uint32_t idx = (uint32_t)px.x, idy = (uint32_t)px.y;
@@ -114,6 +115,7 @@ __global__ __launch_bounds__(256, RT_MIN_WAVES) void k_ris_primary(const KParams
             r[5] = 0; r[6] = 0xffffffffu; r[7] = 0;
         }
     }
+    writeTileCost(P, px.active && t.dst != INF());
     if (P.stats) {
         waveAdd(P.stats + ST_RAYS, rays);
         if (INSTR) {

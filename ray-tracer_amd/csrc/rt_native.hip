@@ -40,7 +40,9 @@ struct rt_ctx_s {
     int statsLevel = 0;  // 0 off, 1 rays + active pixels, 2 all counters (instrumented kernel variants)
     unsigned long long* statsDev = nullptr;  // IK_COUNT x STAT_SHARDS x 8 counters, accumulated until read
     // workgroup -> image block table of the per-pixel kernels (see buildBlockMap)
-    struct BlockMap { int bx, by; uint32_t* dev; unsigned n; };
+    // dev: the static order; dyn: the heaviest-first order k_order_blocks rebuilds after every InitialTrace from the
+    // per-wave hit counts in cost (null when the grid has more regions than that kernel sorts)
+    struct BlockMap { int bx, by; uint32_t* dev; unsigned n; uint32_t* dyn; uint32_t* cost; unsigned nDyn; bool dynValid; };
     std::vector<BlockMap> blockMaps;  // one per band height in use (a multi-GPU host alternates between a few)
     // per-internal-kernel timing with HIP events on the context's stream
     bool timing = false;
@@ -460,7 +462,7 @@ std::vector<uint32_t> buildBlockMap(unsigned bx, unsigned by, int mode) {
 
 // Launch geometry of the per-pixel kernels: 256-thread workgroups, each a 2x2 group of 8x8 tiles, covering the
 // context's row band (whole image by default).  The caller's group counts only have to cover the image.
-int pixelGrid(rt_ctx ctx, KParams& P, int gx, int gy, unsigned* blocks) {
+int pixelGrid(rt_ctx ctx, KParams& P, int gx, int gy, unsigned* blocks, rt_ctx_s::BlockMap** used = nullptr) {
     if (P.ResX <= 0 || P.ResY <= 0) return fail(ctx, RT_ERR_UNBOUND, "constant 'Resolution' is not set");
     if ((int64_t)gx * 8 < P.ResX || (int64_t)gy * 8 < P.ResY)
         return fail(ctx, RT_ERR_INVALID_ARG, "dispatch of %dx%d groups does not cover Resolution %dx%d", gx, gy, P.ResX, P.ResY);
@@ -471,22 +473,46 @@ int pixelGrid(rt_ctx ctx, KParams& P, int gx, int gy, unsigned* blocks) {
     unsigned bx = (unsigned)(P.ResX + 15) / 16, by = (unsigned)(P.row1 - bandY0 + 15) / 16;
     if (bx > 0xffffu || by > 0xffffu) return fail(ctx, RT_ERR_LIMIT, "image too large for the block table");
     static const int mode = [] { const char* e = getenv("RT_BLOCK_MAP"); return e ? atoi(e) : 2; }();
+    static const bool reorder = [] { const char* e = getenv("RT_BLOCK_ORDER"); return e ? atoi(e) != 0 : true; }();
+    P.blocksX = (int)bx;
+    P.blockCost = nullptr;
+    auto use = [&](rt_ctx_s::BlockMap& m) {
+        P.blockMap = m.dynValid ? m.dyn : m.dev;
+        *blocks = m.dynValid ? m.nDyn : m.n;
+        if (used) *used = &m;
+        return RT_OK;
+    };
     for (auto& m : ctx->blockMaps)
-        if (m.bx == (int)bx && m.by == (int)by) { P.blockMap = m.dev; *blocks = m.n; return RT_OK; }
+        if (m.bx == (int)bx && m.by == (int)by) return use(m);
     if (ctx->blockMaps.size() >= 16) {  // bounded: forget the oldest table once nothing can still be reading it
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-        hipError_t e = hipFree(ctx->blockMaps.front().dev);
+        rt_ctx_s::BlockMap& old = ctx->blockMaps.front();
+        hipError_t e = hipFree(old.dev);
+        if (old.dyn) e = hipFree(old.dyn);
+        if (old.cost) e = hipFree(old.cost);
         (void)e;
         ctx->blockMaps.erase(ctx->blockMaps.begin());
     }
     std::vector<uint32_t> map = buildBlockMap(bx, by, mode);
-    rt_ctx_s::BlockMap m = {(int)bx, (int)by, nullptr, (unsigned)map.size()};
+    rt_ctx_s::BlockMap m = {(int)bx, (int)by, nullptr, (unsigned)map.size(), nullptr, nullptr, 0, false};
     HIP_TRY(ctx, hipMalloc((void**)&m.dev, map.size() * 4));
     HIP_TRY(ctx, hipMemcpy(m.dev, map.data(), map.size() * 4, hipMemcpyHostToDevice));
+    const unsigned regions = ((bx + 3) / 4) * ((by + 3) / 4);
+    if (reorder && mode == 2 && regions <= (unsigned)ORDER_MAX_REGIONS) {
+        m.nDyn = (regions + 7) / 8 * 128;
+        HIP_TRY(ctx, hipMalloc((void**)&m.dyn, (size_t)m.nDyn * 4));
+        HIP_TRY(ctx, hipMalloc((void**)&m.cost, (size_t)bx * by * 4 * 4));
+        HIP_TRY(ctx, hipMemset(m.cost, 0, (size_t)bx * by * 4 * 4));
+    }
     ctx->blockMaps.push_back(m);
-    P.blockMap = m.dev;
-    *blocks = m.n;
-    return RT_OK;
+    return use(ctx->blockMaps.back());
+}
+// After InitialTrace's primary-ray kernel: rank the regions by the hit counts it left and switch this grid to the
+// heaviest-first table (used by every later launch on the same grid, including the next frame's InitialTrace).
+void reorderBlocks(rt_ctx ctx, rt_ctx_s::BlockMap* m) {
+    if (!m || !m->dyn) return;
+    hipLaunchKernelGGL(k_order_blocks, dim3(1), dim3(1024), 0, ctx->stream, m->cost, m->bx, m->by, m->dyn, m->nDyn);
+    m->dynValid = true;
 }
 
 // Launch bracket: points the kernel at its counter slot and, when timing is on, records events around it.
@@ -534,7 +560,8 @@ int dispatchReSTIR(rt_shader sh, int kernel, int gx, int gy) {
     memset(&P, 0, sizeof P);
     fillConstants(sh, P);
     unsigned blocks = 0;
-    int rc = pixelGrid(ctx, P, gx, gy, &blocks);
+    rt_ctx_s::BlockMap* grid = nullptr;
+    int rc = pixelGrid(ctx, P, gx, gy, &blocks, &grid);
     if (rc) return rc;
     const int X = P.ResX, Y = P.ResY;
     const int64_t npx = (int64_t)X * Y;
@@ -576,9 +603,16 @@ int dispatchReSTIR(rt_shader sh, int kernel, int gx, int gy) {
             if (!blocks) break;
             size_t ldsBytes = (size_t)WAVES_PER_BLOCK * P.stackDepth * 64 * 4;
             {
+                if (grid) P.blockCost = grid->cost;
                 LaunchScope ls(ctx, IK_PRIMARY, &P);
                 if (instr) hipLaunchKernelGGL(k_primary<true>, dim3(blocks), dim3(256), ldsBytes, ctx->stream, P);
                 else hipLaunchKernelGGL(k_primary<false>, dim3(blocks), dim3(256), ldsBytes, ctx->stream, P);
+            }
+            if (grid && grid->dyn) {  // the candidate kernel and everything after it run heaviest regions first
+                reorderBlocks(ctx, grid);
+                P.blockMap = grid->dyn;
+                blocks = grid->nDyn;
+                P.blockCost = nullptr;
             }
             {
                 LaunchScope ls(ctx, IK_CANDIDATES, &P);
@@ -655,7 +689,8 @@ int dispatchRIS(rt_shader sh, int kernel, int gx, int gy) {
     P.risTriReservoirTestsNum = (int32_t)cWord(sh, "TriReservoirTestsNum");
     P.risEmittingObjectsNum = (int32_t)cWord(sh, "EmittingObjectsNum");
     unsigned blocks = 0;
-    int rc = pixelGrid(ctx, P, gx, gy, &blocks);
+    rt_ctx_s::BlockMap* grid = nullptr;
+    int rc = pixelGrid(ctx, P, gx, gy, &blocks, &grid);
     if (rc) return rc;
     const int X = P.ResX, Y = P.ResY;
     const int64_t npx = (int64_t)X * Y;
@@ -692,9 +727,16 @@ int dispatchRIS(rt_shader sh, int kernel, int gx, int gy) {
         if ((rc = needTex(sh, kernel, "RayHitPoints", false, X, Y, P.rayHitPoints))) return rc;
         if (!blocks) return RT_OK;
         {
+            if (grid) P.blockCost = grid->cost;
             LaunchScope ls(ctx, IK_RIS_PRIMARY, &P);
             if (instr) hipLaunchKernelGGL(k_ris_primary<true>, dim3(blocks), dim3(256), ldsBytes, ctx->stream, P);
             else hipLaunchKernelGGL(k_ris_primary<false>, dim3(blocks), dim3(256), ldsBytes, ctx->stream, P);
+        }
+        if (grid && grid->dyn) {
+            reorderBlocks(ctx, grid);
+            P.blockMap = grid->dyn;
+            blocks = grid->nDyn;
+            P.blockCost = nullptr;
         }
         {
             LaunchScope ls(ctx, IK_RIS_CANDIDATES, &P);
@@ -808,7 +850,7 @@ void rt_destroy(rt_ctx ctx) {
         if (pr.objRoot) e = hipFree(pr.objRoot);
     }
     if (ctx->statsDev) e = hipFree(ctx->statsDev);
-    for (auto& m : ctx->blockMaps) e = hipFree(m.dev);
+    for (auto& m : ctx->blockMaps) { e = hipFree(m.dev); if (m.dyn) e = hipFree(m.dyn); if (m.cost) e = hipFree(m.cost); }
     for (auto& t : ctx->pending) { e = hipEventDestroy(t.start); e = hipEventDestroy(t.stop); }
     for (auto ev : ctx->freeEvents) e = hipEventDestroy(ev);
     e = hipStreamDestroy(ctx->stream);
