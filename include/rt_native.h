@@ -141,8 +141,8 @@ void rt_texture_release(rt_texture tex);
 /* ---- multi-GPU row access (no counterpart in the reference) ----------------------------------------------- */
 
 /* Device memory holding image rows [row0, row1) of a per-pixel buffer (`width` records per row) or of a texture,
- * in the layout the library currently keeps it in: a 52-byte-record buffer is either one contiguous run (record
- * layout) or four runs (plane layout).  A multi-GPU host maps the border rows of the reservoir buffers and of
+ * in the layout the library currently keeps it in: a 52-byte-record buffer is one contiguous run (the ABI layout, or
+ * the padded 64-byte records the reservoirs gathered by SpatialReusePass are kept in) or four runs (plane layout).  A multi-GPU host maps the border rows of the reservoir buffers and of
  * DepthBuffer right before each exchange and sends/receives them between the per-GPU processes (RCCL); row r of
  * one process's buffer corresponds to row r of every other's, because each process keeps full-frame buffers and
  * only renders its band.  The pointers are valid until the next call that uploads to or releases the object. */

@@ -1108,22 +1108,27 @@ __global__ void k_recs_to_aos(Recs rc, float* aos) {
 // Regions are ranked by their hit pixels in steps of 64 (a counting sort; the order inside a step is whatever the
 // atomics give: any permutation renders the same image) and dealt to the 8 XCDs in that order; every XCD still walks
 // whole regions.  One workgroup; `dyn` has ceil(regions / 8) * 128 entries.
+#ifndef RT_REGION
+#define RT_REGION 4   // blocks per side of a region
+#endif
 constexpr int ORDER_MAX_REGIONS = 4096;
 __global__ __launch_bounds__(1024) void k_order_blocks(const uint32_t* costW, int BX, int BY, uint32_t* dyn, unsigned nDyn) {
     __shared__ uint32_t hist[66], order[ORDER_MAX_REGIONS];
     __shared__ uint8_t bucketOf[ORDER_MAX_REGIONS];
-    const int RX = (BX + 3) / 4, RY = (BY + 3) / 4, R = RX * RY;
+    constexpr int RS = RT_REGION;
+    const int RX = (BX + RS - 1) / RS, RY = (BY + RS - 1) / RS, R = RX * RY;
     const int t = (int)threadIdx.x;
     if (t < 66) hist[t] = 0;
     __syncthreads();
     for (int r = t; r < R; r += 1024) {
         const int ri = r % RX, rj = r / RX;
         uint32_t c = 0;
-        for (int y = rj * 4; y < rj * 4 + 4 && y < BY; y++)
-            for (int x = ri * 4; x < ri * 4 + 4 && x < BX; x++) {
+        for (int y = rj * RS; y < rj * RS + RS && y < BY; y++)
+            for (int x = ri * RS; x < ri * RS + RS && x < BX; x++) {
                 const uint32_t* w = costW + ((size_t)y * BX + x) * 4;
                 c += w[0] + w[1] + w[2] + w[3];
             }
+        c = c * 16 / (RS * RS);  // as if the region had 16 blocks
         const uint32_t step = c / 64 > 64 ? 64 : c / 64;
         bucketOf[r] = (uint8_t)(64 - step);  // bucket 0 = heaviest
         atomicAdd(&hist[64 - step], 1u);
@@ -1137,11 +1142,11 @@ __global__ __launch_bounds__(1024) void k_order_blocks(const uint32_t* costW, in
     for (int r = t; r < R; r += 1024) order[atomicAdd(&hist[bucketOf[r]], 1u)] = (uint32_t)r;
     __syncthreads();
     for (unsigned m = (unsigned)t; m < nDyn; m += 1024) {
-        const unsigned xcd = m % 8, j = m / 8, ord = (j / 16) * 8 + xcd, k = j % 16;
+        const unsigned xcd = m % 8, j = m / 8, ord = (j / (RS * RS)) * 8 + xcd, k = j % (RS * RS);
         uint32_t entry = 0xffffffffu;
         if ((int)ord < R) {
             const uint32_t r = order[ord];
-            const int x = (int)(r % RX) * 4 + (int)(k % 4), y = (int)(r / RX) * 4 + (int)(k / 4);
+            const int x = (int)(r % RX) * RS + (int)(k % RS), y = (int)(r / RX) * RS + (int)(k / RS);
             if (x < BX && y < BY) entry = (uint32_t)y << 16 | (uint32_t)x;
         }
         dyn[m] = entry;

@@ -435,7 +435,7 @@ std::vector<uint32_t> buildBlockMap(unsigned bx, unsigned by, int mode) {
             pos += len;
         }
     } else {
-        const unsigned RW = 4, RH = 4;  // region = 4x4 blocks = 64x64 pixels
+        const unsigned RW = RT_REGION, RH = RT_REGION;  // region = 4x4 blocks = 64x64 pixels
         unsigned rx = (bx + RW - 1) / RW, ry = (by + RH - 1) / RH, region = 0;
         for (unsigned j = 0; j < ry; j++)
             for (unsigned i = 0; i < rx; i++, region++) {
@@ -497,9 +497,9 @@ int pixelGrid(rt_ctx ctx, KParams& P, int gx, int gy, unsigned* blocks, rt_ctx_s
     rt_ctx_s::BlockMap m = {(int)bx, (int)by, nullptr, (unsigned)map.size(), nullptr, nullptr, 0, false};
     HIP_TRY(ctx, hipMalloc((void**)&m.dev, map.size() * 4));
     HIP_TRY(ctx, hipMemcpy(m.dev, map.data(), map.size() * 4, hipMemcpyHostToDevice));
-    const unsigned regions = ((bx + 3) / 4) * ((by + 3) / 4);
+    const unsigned regions = ((bx + RT_REGION - 1) / RT_REGION) * ((by + RT_REGION - 1) / RT_REGION);
     if (reorder && mode == 2 && regions <= (unsigned)ORDER_MAX_REGIONS) {
-        m.nDyn = (regions + 7) / 8 * 128;
+        m.nDyn = (regions + 7) / 8 * (8 * RT_REGION * RT_REGION);
         HIP_TRY(ctx, hipMalloc((void**)&m.dyn, (size_t)m.nDyn * 4));
         HIP_TRY(ctx, hipMalloc((void**)&m.cost, (size_t)bx * by * 4 * 4));
         HIP_TRY(ctx, hipMemset(m.cost, 0, (size_t)bx * by * 4 * 4));
