@@ -150,10 +150,33 @@ def main():
     W, H = args.width, args.height
 
     if world > 1:
+        import torch
+        import torch.distributed as dist
         mg = importlib.import_module("ray-tracer_amd.multigpu")
+        runner = None
         if args.exchange == "rccl":
-            runner = mg.RcclRunner(rt, scene, cfg, rank, world, local_rank)
-        else:
+            # the side channel (unique id, timing reductions) first, so that the ranks can agree on whether the
+            # native loop came up everywhere; if it did not on some rank, all of them take the torch.distributed path
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+            why = ""
+            try:
+                runner = mg.RcclRunner(rt, scene, cfg, rank, world, local_rank)
+            except Exception as e:  # noqa: BLE001 - any failure means "use the other driver"
+                why = f"{type(e).__name__}: {e}"
+            ok = torch.tensor([1 if runner else 0])
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            if int(ok[0]) == 0:
+                if ris:
+                    sys.exit(f"rank {rank}: the native multi-GPU loop failed to start ({why or 'on another rank'})")
+                print(f"rank {rank}: native RCCL loop unavailable ({why or 'failed on another rank'}); "
+                      f"using torch.distributed", file=sys.stderr)
+                if runner:
+                    runner.close()
+                    runner = None
+                elif dist.is_initialized():
+                    dist.destroy_process_group()
+                args.exchange = "torch"
+        if runner is None:
             runner = mg.DistributedRunner(rt, scene, cfg, rank, world, local_rank)
     else:
         runner = SingleRunner(rt, scene, cfg)
