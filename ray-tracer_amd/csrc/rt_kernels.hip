@@ -1113,22 +1113,21 @@ __global__ void k_recs_to_aos(Recs rc, float* aos) {
 #endif
 constexpr int ORDER_MAX_REGIONS = 4096;
 __global__ __launch_bounds__(1024) void k_order_blocks(const uint32_t* costW, int BX, int BY, uint32_t* dyn, unsigned nDyn) {
-    __shared__ uint32_t hist[66], order[ORDER_MAX_REGIONS];
+    __shared__ uint32_t hist[66], order[ORDER_MAX_REGIONS], regionCost[ORDER_MAX_REGIONS];
     __shared__ uint8_t bucketOf[ORDER_MAX_REGIONS];
     constexpr int RS = RT_REGION;
     const int RX = (BX + RS - 1) / RS, RY = (BY + RS - 1) / RS, R = RX * RY;
     const int t = (int)threadIdx.x;
     if (t < 66) hist[t] = 0;
+    for (int r = t; r < R; r += 1024) regionCost[r] = 0;
+    __syncthreads();
+    for (int b = t; b < BX * BY; b += 1024) {  // one 16-byte load per block: its four waves' hit counts
+        const uint4 w = ((const uint4*)costW)[b];
+        atomicAdd(&regionCost[(b / BX / RS) * RX + (b % BX) / RS], w.x + w.y + w.z + w.w);
+    }
     __syncthreads();
     for (int r = t; r < R; r += 1024) {
-        const int ri = r % RX, rj = r / RX;
-        uint32_t c = 0;
-        for (int y = rj * RS; y < rj * RS + RS && y < BY; y++)
-            for (int x = ri * RS; x < ri * RS + RS && x < BX; x++) {
-                const uint32_t* w = costW + ((size_t)y * BX + x) * 4;
-                c += w[0] + w[1] + w[2] + w[3];
-            }
-        c = c * 16 / (RS * RS);  // as if the region had 16 blocks
+        const uint32_t c = regionCost[r] * 16 / (RS * RS);  // as if the region had 16 blocks
         const uint32_t step = c / 64 > 64 ? 64 : c / 64;
         bucketOf[r] = (uint8_t)(64 - step);  // bucket 0 = heaviest
         atomicAdd(&hist[64 - step], 1u);
