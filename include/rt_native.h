@@ -3,7 +3,7 @@
  * The reference has no plugin interface of its own: its host (C#) drives the kernels through Unity's
  * ComputeShader / ComputeBuffer / RenderTexture objects.  Each entry point below replaces exactly one of those
  * Unity calls as the reference makes it, with the same names for kernels, constants, buffers, textures and
- * keywords, so a host can P/Invoke this library instead of Unity's compute back end (binding: INTEGRATION.md).
+ * keywords, so a host can P/Invoke this library instead of Unity's compute back end.
  * Citations are paths under BVH_ReSTIR_DL/Assets/Scripts/ unless they start with BVH_RIS_DL.
  *
  * Conventions
