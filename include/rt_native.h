@@ -182,6 +182,9 @@ typedef struct {
     rt_dispatch_stats stats;
 } rt_kernel_profile;
 int rt_profile_enable(rt_ctx ctx, int timing);
+/* Restricts the event brackets to the launches of one named kernel (NULL or "" = every kernel again).  A pair of
+ * events costs a few microseconds of stream time per launch, which matters when a whole frame is being timed. */
+int rt_profile_select(rt_ctx ctx, const char* kernel_name);
 int rt_profile_reset(rt_ctx ctx);
 int rt_profile_get(rt_ctx ctx, const char* kernel_name, rt_kernel_profile* out);
 

@@ -79,7 +79,7 @@ def native_lib():
             "rt_texture_release": (None, [vp]),
             "rt_buffer_map_rows": (ci, [vp, ci, ci, ci, vp, C.POINTER(ci)]), "rt_texture_map_rows": (ci, [vp, ci, ci, vp]),
             "rt_enable_stats": (ci, [vp, ci]), "rt_get_stats": (ci, [vp, ci, vp]),
-            "rt_profile_enable": (ci, [vp, ci]), "rt_profile_reset": (ci, [vp]), "rt_profile_get": (ci, [vp, cs, vp]),
+            "rt_profile_enable": (ci, [vp, ci]), "rt_profile_select": (ci, [vp, cs]), "rt_profile_reset": (ci, [vp]), "rt_profile_get": (ci, [vp, cs, vp]),
         }
         for name, (res, args) in sig.items():
             fn = getattr(lib, name)
@@ -449,7 +449,9 @@ class RtContext:
         self.check(self.lib.rt_texture_map_rows(tex, row0, row1, C.byref(seg)), "rt_texture_map_rows")
         return [(seg.ptr, seg.bytes)]
 
-    def profile_enable(self, timing):
+    def profile_enable(self, timing, only=None):
+        """Brackets launches with HIP events; only: name of the single kernel to time (None = all of them)."""
+        self.check(self.lib.rt_profile_select(self.h, only.encode() if only else None), "rt_profile_select")
         self.check(self.lib.rt_profile_enable(self.h, 1 if timing else 0), "rt_profile_enable")
 
     def profile_reset(self):

@@ -46,6 +46,7 @@ struct rt_ctx_s {
     std::vector<BlockMap> blockMaps;  // one per band height in use (a multi-GPU host alternates between a few)
     // per-internal-kernel timing with HIP events on the context's stream
     bool timing = false;
+    int timingOnly = -1;  // IK_* of the only kernel whose launches are bracketed by events, -1 = all
     struct Timed { int kernel; hipEvent_t start, stop; };
     std::vector<Timed> pending;
     std::vector<hipEvent_t> freeEvents;
@@ -523,7 +524,7 @@ struct LaunchScope {
     LaunchScope(rt_ctx c, int k, KParams* P) : ctx(c), ik(k) {
         if (P) { P->stats = ctx->statsLevel > 0 ? ctx->statsDev + (size_t)k * STAT_SHARDS * 8 : nullptr; P->statsLevel = ctx->statsLevel; }
         ctx->launches[k]++;
-        if (!ctx->timing) return;
+        if (!ctx->timing || (ctx->timingOnly >= 0 && ctx->timingOnly != k)) return;
         auto take = [&]() -> hipEvent_t {
             if (!ctx->freeEvents.empty()) { hipEvent_t e = ctx->freeEvents.back(); ctx->freeEvents.pop_back(); return e; }
             hipEvent_t e = nullptr;
@@ -1192,6 +1193,16 @@ int rt_profile_enable(rt_ctx ctx, int timing) {
     if (rc) return rc;
     if ((rc = drainTiming(ctx))) return rc;
     ctx->timing = timing != 0;
+    return RT_OK;
+}
+int rt_profile_select(rt_ctx ctx, const char* kernel_name) {
+    if (!ctx) return RT_ERR_INVALID_ARG;
+    int ik = -1;
+    if (kernel_name && *kernel_name) {
+        for (int i = 0; i < IK_COUNT; i++) if (!strcmp(kernel_name, IK_NAMES[i])) ik = i;
+        if (ik < 0) return fail(ctx, RT_ERR_INVALID_ARG, "unknown kernel name '%s'", kernel_name);
+    }
+    ctx->timingOnly = ik;
     return RT_OK;
 }
 int rt_profile_reset(rt_ctx ctx) {
