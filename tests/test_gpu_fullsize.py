@@ -67,6 +67,43 @@ def test_deterministic_and_band_invariant(gpu_ctx, scene_80k):
         banded.close()
 
 
+def test_4k_two_bands_equal_full_frame(gpu_ctx, scene_80k):
+    """3840x2160 (2040 regions in the heaviest-first table): the frame rendered as two bands, through the driver's
+    own frame loop restricted to a band at a time, equals the frame rendered whole."""
+    cfg = rt.default_config()
+    cfg.Resolution[0], cfg.Resolution[1] = 3840, 2160
+    names_b, names_t = ("Candidates", "HitInfos"), ("Result", "AccumulatedResult", "DepthBuffer")
+
+    def snap(drv):
+        drv.ctx.sync()
+        return {**{n: drv.buffer(n) for n in names_b}, **{n: drv.texture(n) for n in names_t}}
+
+    full = rt.Driver(gpu_ctx, cfg, scene_80k)
+    for _ in range(2):
+        full.render_frame()
+    want = snap(full)
+    full.close()
+    assert np.isfinite(want["DepthBuffer"]).any() and not np.isfinite(want["DepthBuffer"]).all()
+
+    banded = rt.Driver(gpu_ctx, cfg, scene_80k)
+    bands = [(0, 1000), (1000, 2160)]
+    try:
+        for _ in range(2):
+            banded.update_per_frame()
+            for step in ([lambda: banded.run_stage(0)], [lambda: banded.run_stage(1)],
+                         *[[lambda i=i: banded.run_spatial_pass(i)] for i in range(cfg.SpatialReuseIterations)],
+                         [banded.run_transfer], [lambda: banded.run_stage(3), banded.run_post_processing]):
+                for b in bands:
+                    gpu_ctx.set_row_band(*b)
+                    for f in step:
+                        f()
+        gpu_ctx.set_row_band(0, 0)
+        assert_equal_snap(snap(banded), want, "4K banded run")
+    finally:
+        gpu_ctx.set_row_band(0, 0)
+        banded.close()
+
+
 def test_ray_accounting(gpu_ctx, scene_80k):
     cfg = rt.default_config()
     drv = rt.Driver(gpu_ctx, cfg, scene_80k)
@@ -85,6 +122,14 @@ def test_ray_accounting(gpu_ctx, scene_80k):
         res = drv.texture("Result")
         sky = ~np.isfinite(depth)
         assert np.array_equal(res[sky][:, :3], np.broadcast_to(np.float32([0.5, 0.7, 1.0]), (int(sky.sum()), 3)))
+        # event brackets restricted to one kernel: the others are still counted but not timed
+        gpu_ctx.profile_reset()
+        gpu_ctx.profile_enable(True, only="trace_rays")
+        drv.render_frame()
+        p = gpu_ctx.profile()
+        gpu_ctx.profile_enable(False)
+        assert p["trace_rays"]["ms"] > 0 and p["primary"]["ms"] == 0 and p["primary"]["launches"] == 1
+        assert p["primary"]["rays"] == 1920 * 1080
     finally:
         gpu_ctx.enable_stats(0)
         drv.close()
