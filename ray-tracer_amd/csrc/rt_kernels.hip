@@ -344,12 +344,11 @@ DEV void travInternal(const KParams& P, TravState& s, Trav& t, uint32_t* stk) {
     const bool aFirst = dstA < dstB;  // the nearer child is visited first
     const uint32_t eNear = aFirst ? eA : eB, eFar = aFirst ? eB : eA;
     const bool nearHit = (aFirst ? dstA : dstB) < s.best, farHit = (aFirst ? dstB : dstA) < s.best;
-    if (nearHit) {
-        if (farHit) { if (s.sp < P.stackDepth) stk[s.sp * 64] = eFar; s.sp++; }
-        s.e = eNear;
-        if (INSTR) t.pops++;
-    } else if (farHit) {
-        s.e = eFar;
+    // Written flat (one predicated push, one predicated pop) instead of as nested branches: fewer exec-mask
+    // regions per step.  A far child can pass while the near one fails only when a distance is NaN.
+    if (nearHit && farHit) { if (s.sp < P.stackDepth) stk[s.sp * 64] = eFar; s.sp++; }
+    if (nearHit || farHit) {
+        s.e = nearHit ? eNear : eFar;
         if (INSTR) t.pops++;
     } else {
         travPop<INSTR>(P, s, t, stk);
@@ -408,13 +407,16 @@ DEV void travLeaf(const KParams& P, TravState& s, Trav& t, const uint32_t* stk) 
 template <bool INSTR, bool RIS>
 DEV void travTrip(const KParams& P, TravState& s, Trav& t, uint32_t* stk, bool& alive) {
     if (alive && s.e == ENTRY_NONE) alive = travService<INSTR, RIS>(P, s, t, stk);
-    for (;;) {
-        const bool isInt = alive && s.e != ENTRY_NONE && (s.e & LEAF_BITS) == 0;
-        if (__builtin_amdgcn_ballot_w64(isInt) == 0) break;
+    // The phase is left once at least RT_LEAF_NUM / RT_LEAF_DEN of the lanes still at work wait for a leaf or for
+    // service, i.e. once the lanes holding an internal entry are few enough (the live lanes do not change in it).
+    const int nAlive = __builtin_popcountll(__builtin_amdgcn_ballot_w64(alive));
+    bool isInt = alive && s.e != ENTRY_NONE && (s.e & LEAF_BITS) == 0;
+    int nInt = __builtin_popcountll(__builtin_amdgcn_ballot_w64(isInt));
+    while (nInt != 0) {
         if (isInt) travInternal<INSTR, RIS>(P, s, t, stk);
-        // leave the phase once at least half of the lanes still at work wait for a leaf or for service
-        const unsigned long long waitMask = __builtin_amdgcn_ballot_w64(alive && (s.e == ENTRY_NONE || (s.e & LEAF_BITS) != 0));
-        if (RT_LEAF_DEN * __builtin_popcountll(waitMask) >= RT_LEAF_NUM * __builtin_popcountll(__builtin_amdgcn_ballot_w64(alive))) break;
+        isInt = alive && s.e != ENTRY_NONE && (s.e & LEAF_BITS) == 0;
+        nInt = __builtin_popcountll(__builtin_amdgcn_ballot_w64(isInt));
+        if (RT_LEAF_DEN * (nAlive - nInt) >= RT_LEAF_NUM * nAlive) break;
     }
     if (alive && s.e != ENTRY_NONE && (s.e & LEAF_BITS) != 0) travLeaf<INSTR, RIS>(P, s, t, stk);
 }
