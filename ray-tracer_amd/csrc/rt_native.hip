@@ -42,7 +42,7 @@ struct rt_ctx_s {
     // workgroup -> image block table of the per-pixel kernels (see buildBlockMap)
     // dev: the static order; dyn: the heaviest-first order k_order_blocks rebuilds after every InitialTrace from the
     // per-wave hit counts in cost (null when the grid has more regions than that kernel sorts)
-    struct BlockMap { int bx, by; uint32_t* dev; unsigned n; uint32_t* dyn; uint32_t* cost; unsigned nDyn; bool dynValid; };
+    struct BlockMap { int bx, by; uint32_t* dev; unsigned n; uint32_t* dyn; uint32_t* cost; unsigned nDyn; bool dynValid; unsigned age; };
     std::vector<BlockMap> blockMaps;  // one per band height in use (a multi-GPU host alternates between a few)
     // per-internal-kernel timing with HIP events on the context's stream
     bool timing = false;
@@ -495,7 +495,7 @@ int pixelGrid(rt_ctx ctx, KParams& P, int gx, int gy, unsigned* blocks, rt_ctx_s
         ctx->blockMaps.erase(ctx->blockMaps.begin());
     }
     std::vector<uint32_t> map = buildBlockMap(bx, by, mode);
-    rt_ctx_s::BlockMap m = {(int)bx, (int)by, nullptr, (unsigned)map.size(), nullptr, nullptr, 0, false};
+    rt_ctx_s::BlockMap m = {(int)bx, (int)by, nullptr, (unsigned)map.size(), nullptr, nullptr, 0, false, 0};
     HIP_TRY(ctx, hipMalloc((void**)&m.dev, map.size() * 4));
     HIP_TRY(ctx, hipMemcpy(m.dev, map.data(), map.size() * 4, hipMemcpyHostToDevice));
     const unsigned regions = ((bx + RT_REGION - 1) / RT_REGION) * ((by + RT_REGION - 1) / RT_REGION);
@@ -512,6 +512,9 @@ int pixelGrid(rt_ctx ctx, KParams& P, int gx, int gy, unsigned* blocks, rt_ctx_s
 // heaviest-first table (used by every later launch on the same grid, including the next frame's InitialTrace).
 void reorderBlocks(rt_ctx ctx, rt_ctx_s::BlockMap* m) {
     if (!m || !m->dyn) return;
+    // the ranking moves slowly from frame to frame: refresh it on the first frame and then every eighth (a stale
+    // order is still a complete one; it only costs a little balance after a camera cut)
+    if (m->dynValid && (++m->age % 8) != 0) return;
     hipLaunchKernelGGL(k_order_blocks, dim3(1), dim3(1024), 0, ctx->stream, m->cost, m->bx, m->by, m->dyn, m->nDyn);
     m->dynValid = true;
 }
