@@ -465,9 +465,17 @@ DEV HitInfo resolveHit(const KParams& P, const Trav& t, v3 wpos, v3 wdir) {
 // retires only ~one atomic per 12 ns).  The host sums the copies.
 constexpr int STAT_SHARDS = 64;
 DEV void waveAdd(unsigned long long* dst, uint32_t v) {
-    // butterfly sum over the 64 lanes (inactive lanes contribute their own v, so callers pass 0 for them)
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-    if ((threadIdx.x & 63) == 0 && v) atomicAdd(dst + (blockIdx.x % STAT_SHARDS) * 8, (unsigned long long)v);
+    // Sum over the 64 lanes (callers pass 0 for lanes that have nothing to add).  The always-on ray counter adds 0..7
+    // per lane: three ballots give its sum; anything larger takes the butterfly (cross-lane moves through LDS).
+    if (__builtin_amdgcn_ballot_w64(v != 0) == 0) return;
+    if (__builtin_amdgcn_ballot_w64(v > 7u) == 0) {
+        v = (uint32_t)(__builtin_popcountll(__builtin_amdgcn_ballot_w64((v & 1u) != 0)) +
+                       2 * __builtin_popcountll(__builtin_amdgcn_ballot_w64((v & 2u) != 0)) +
+                       4 * __builtin_popcountll(__builtin_amdgcn_ballot_w64((v & 4u) != 0)));
+    } else {
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    }
+    if ((threadIdx.x & 63) == 0) atomicAdd(dst + (blockIdx.x % STAT_SHARDS) * 8, (unsigned long long)v);
 }
 // Diagnostics (instrumented variants only): lifetime and loop-trip counts of each wave of a launch.
 DEV void writeWaveProfile(const KParams& P, unsigned long long tStart, uint32_t iters) {
