@@ -118,6 +118,8 @@ def main():
                          "10 discs of 1000 emissive triangles: the deep-BVH configuration.  unique: the same grid with "
                          "every dragon a distinct (vertex-jittered) mesh with its own BVH: 10 M stored triangles, "
                          "about 1.4 GB of nodes, triangles and vertices")
+    ap.add_argument("--emissive-fans", action="store_true",
+                    help="instanced / unique scenes: emissive discs as plain 1000-triangle fans instead of 40 sectors x 13 rings")
     ap.add_argument("--project", choices=("restir", "ris"), default="restir",
                     help="ris: the RIS project's frame (GenerateCandidates with 32 candidates per pixel, TraceRays "
                          "drawing 32 of them, AccumulateFrames) instead of the ReSTIR sequence")
@@ -139,7 +141,8 @@ def main():
     rt = importlib.import_module("ray-tracer_amd")
     if args.scene != "80k":
         scene = rt.build_scene_instanced(grid=(16, 8), emissive_objects=10, emissive_tris=1000,
-                                         unique=args.scene == "unique", subdivide=not args.small_scene)
+                                         unique=args.scene == "unique", subdivide=not args.small_scene,
+                                         emissive_fans=args.emissive_fans)
     else:
         scene = rt.build_scene_s0(subdivide=not args.small_scene)
     ris = args.project == "ris"
@@ -262,7 +265,7 @@ def main():
             "config": {"workload": (f"{proj} 80kScene* ({'8.7k' if args.small_scene else '78k'}-triangle dragon stand-in "
                                     f"+ Suzanne light)" if args.scene == "80k" else
                                     f"{proj} {args.scene} 80kScene* (128 dragon "
-                                    f"{'instances' if args.scene == 'instanced' else 'meshes, each distinct'} + 10 emissive discs)") +
+                                    f"{'instances' if args.scene == 'instanced' else 'meshes, each distinct'} + 10 emissive discs{' (fans)' if args.emissive_fans else ''})") +
                                    (f" {W}x{H}, RIS project: {RIS_TOT} candidates per pixel, {RIS_TESTS} drawn" if ris else
                                     f" {W}x{H}, temporal + 3 spatial reuse passes, VIS_REUSE+BRDF"),
                        "instanced_triangles": int(sum(scene.arrays()["ComponentDatas"][o["bvStartIndex"]][1]

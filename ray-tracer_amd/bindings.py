@@ -179,7 +179,7 @@ def host_lib():
         fp = C.POINTER(C.c_float)
         sig = {
             "rth_mesh_create": (vp, [vp, ci, vp, ci]), "rth_mesh_load": (vp, [cs]), "rth_mesh_subdivide9": (vp, [vp]),
-            "rth_mesh_jitter": (vp, [vp, C.c_uint32, C.c_float]), "rth_mesh_disc": (vp, [ci]),
+            "rth_mesh_jitter": (vp, [vp, C.c_uint32, C.c_float]), "rth_mesh_disc": (vp, [ci]), "rth_mesh_ring_disc": (vp, [ci]),
             "rth_mesh_free": (None, [vp]), "rth_mesh_counts": (ci, [vp, C.POINTER(ci), C.POINTER(ci)]),
             "rth_mesh_vertices": (vp, [vp]), "rth_mesh_triangles": (vp, [vp]),
             "rth_scene_create": (vp, [ci, ci]), "rth_scene_free": (None, [vp]),
@@ -252,8 +252,9 @@ class Mesh:
         return cls(host_lib().rth_mesh_load(path.encode()))
 
     @classmethod
-    def disc(cls, ntris):
-        return cls(host_lib().rth_mesh_disc(ntris))
+    def disc(cls, ntris, rings=False):
+        """Unit disc facing +z: a fan of ntris triangles, or (rings=True) sectors x rings of similar-sized ones."""
+        return cls(host_lib().rth_mesh_ring_disc(ntris) if rings else host_lib().rth_mesh_disc(ntris))
 
     @classmethod
     def from_arrays(cls, verts, tris):

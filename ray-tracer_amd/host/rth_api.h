@@ -30,6 +30,8 @@ rth_mesh rth_mesh_subdivide9(rth_mesh m);
 rth_mesh rth_mesh_jitter(rth_mesh m, uint32_t seed, float amplitude);
 /* Procedural fan of `ntris` triangles around the z axis (unit radius), facing +z.  Used for emissive quads/discs. */
 rth_mesh rth_mesh_disc(int ntris);
+/* The same disc as sectors x rings of similar-sized triangles (ntris = sectors * (2 * rings - 1)). */
+rth_mesh rth_mesh_ring_disc(int ntris);
 void rth_mesh_free(rth_mesh m);
 int rth_mesh_counts(rth_mesh m, int* nverts, int* ntris);
 const rt_vertex* rth_mesh_vertices(rth_mesh m);

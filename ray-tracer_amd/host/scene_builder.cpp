@@ -160,6 +160,35 @@ rth_mesh rth_mesh_disc(int ntris) {
     return m;
 }
 
+// The same disc tessellated as `sectors` wedges x rings: a fan of `sectors` triangles in the middle, two triangles per
+// sector in every further ring, i.e. sectors * (2 * rings - 1) triangles of similar size (a fan of many triangles is
+// all slivers through one vertex, whose boxes overlap: every ray near the disc then tests dozens of them).  `ntris`
+// is split as sectors * (2 * rings - 1) with the largest odd factor not above sqrt(2 * ntris); a count without such
+// a factor above 1 gives the plain fan.
+rth_mesh rth_mesh_ring_disc(int ntris) {
+    if (ntris < 1) return nullptr;
+    int odd = 1;
+    for (int d = 3; (long long)d * d <= 2LL * ntris; d += 2) if (ntris % d == 0) odd = d;
+    const int rings = (odd + 1) / 2, sectors = ntris / odd;
+    if (rings < 2 || sectors < 3) return rth_mesh_disc(ntris);
+    rth_mesh m = new rth_mesh_s;
+    m->verts.push_back({{0, 0, 0}, {0.5f, 0.5f}});
+    for (int k = 1; k <= rings; k++)
+        for (int i = 0; i < sectors; i++) {
+            double a = 6.283185307179586 * i / sectors, r = (double)k / rings;
+            float cx = (float)(r * cos(a)), cy = (float)(r * sin(a));
+            m->verts.push_back({{cx, cy, 0}, {0.5f + 0.5f * cx, 0.5f + 0.5f * cy}});
+        }
+    auto v = [&](int ring, int i) { return 1 + (ring - 1) * sectors + i % sectors; };
+    for (int i = 0; i < sectors; i++) { m->tris.push_back(0); m->tris.push_back(v(1, i)); m->tris.push_back(v(1, i + 1)); }
+    for (int k = 2; k <= rings; k++)
+        for (int i = 0; i < sectors; i++) {  // both halves of the quad face +z like the fan
+            m->tris.push_back(v(k - 1, i)); m->tris.push_back(v(k, i)); m->tris.push_back(v(k, i + 1));
+            m->tris.push_back(v(k - 1, i)); m->tris.push_back(v(k, i + 1)); m->tris.push_back(v(k - 1, i + 1));
+        }
+    return m;
+}
+
 void rth_mesh_free(rth_mesh m) { delete m; }
 int rth_mesh_counts(rth_mesh m, int* nverts, int* ntris) {
     if (!m) return -1;

@@ -39,9 +39,10 @@ def build_scene_s0(subdivide=True, dragon_depth=None, light_brightness=40000.0, 
 
 
 def build_scene_instanced(grid=(16, 8), emissive_objects=10, emissive_tris=1000, unique=True, subdivide=True,
-                          max_depth_scene_bvh=16, threads=0):
+                          max_depth_scene_bvh=16, threads=0, emissive_fans=False):
     """The deep-BVH scene: a grid of dragons (each vertex-jittered so it is distinct geometry when unique=True)
-    lit by discs of emissive triangles."""
+    lit by discs of emissive triangles (sectors x rings; emissive_fans=True: plain triangle fans, whose slivers
+    through one vertex make every ray near a disc test dozens of triangles)."""
     base = Mesh.load(os.path.join(ASSET_DIR, "dragon8k.rtmesh"))
     if subdivide:
         base = base.subdivide9()
@@ -56,7 +57,7 @@ def build_scene_instanced(grid=(16, 8), emissive_objects=10, emissive_tris=1000,
             s.add_object(mid, (-4 + 9.0 * (i - gx / 2), -2 + 9.0 * (j - gy / 2) * 0.0 + 0.0, 13 + 9.0 * j), (0, 0, 0),
                          (12, 12, 12), 1, 24 if subdivide else 18)
             k += 1
-    disc = Mesh.disc(emissive_tris)
+    disc = Mesh.disc(emissive_tris, rings=not emissive_fans)
     md = s.add_mesh(disc)
     for e in range(emissive_objects):
         s.add_object(md, (-4 + 9.0 * gx * (e / max(1, emissive_objects - 1) - 0.5), 12.0, 13 + 4.5 * gy), (90, 0, 0),
