@@ -96,11 +96,19 @@ def cpu_baseline(rt, scene, cfg, frames, threads):
         orc.render_frame()
     dt = time.perf_counter() - t0
     c = orc.take_counters()
-    return {"value": c["rays"] / 1e6 / dt, "unit": "Mrays/s", "cores": threads, "kind": "port",
-            "sample": f"{frames} full {'RIS' if ris else 'ReSTIR'} frame(s) (frame index 1..{frames}) of the same "
-                      f"{cfg.Resolution[0]}x{cfg.Resolution[1]} workload, "
-                      f"{dt / frames * 1e3:.0f} ms/frame on {threads} threads",
-            "ms_per_frame": dt / frames * 1e3}
+    out = {"value": c["rays"] / 1e6 / dt, "unit": "Mrays/s", "cores": threads, "kind": "port",
+           "sample": f"{frames} full {'RIS' if ris else 'ReSTIR'} frame(s) (frame index 1..{frames}) of the same "
+                     f"{cfg.Resolution[0]}x{cfg.Resolution[1]} workload, "
+                     f"{dt / frames * 1e3:.0f} ms/frame on {threads} threads",
+           "ms_per_frame": dt / frames * 1e3}
+    if threads > 1:   # one more frame on a single thread: the per-core figure
+        orc.threads = 1
+        t0 = time.perf_counter()
+        orc.render_frame()
+        dt1 = time.perf_counter() - t0
+        out["single_thread"] = {"value": orc.take_counters()["rays"] / 1e6 / dt1, "unit": "Mrays/s",
+                                "sample": f"1 further frame, {dt1 * 1e3:.0f} ms"}
+    return out
 
 
 def main():
@@ -257,6 +265,8 @@ def main():
                         "unit": "GB/s", "frac": d["achieved_GBs"] / HBM_PEAK_GBS,
                         "traffic": None if ris else pmc_traffic(dominant, W, H, world, args.small_scene, args.scene),
                         "avg_launch_ms": d["avg_ms"], "algorithmic_MB_per_launch": d["algorithmic_MB_per_launch"]}
+            if roofline["traffic"]:   # what actually crossed the HBM interface, as a rate
+                roofline["hbm_GBs_from_pmc"] = roofline["traffic"] / 1e9 / (d["avg_ms"] / 1e3)
         out = {
             "metric": "Mrays/s (primary+shadow) " + ("RIS DL" if ris else "ReSTIR DL") + ", 80kScene 1080p",
             "value": rays_total / 1e6 / dt_max, "unit": "Mrays/s", "n_gpus": world, "steps": args.steps,
