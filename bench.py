@@ -267,6 +267,10 @@ def main():
                         "avg_launch_ms": d["avg_ms"], "algorithmic_MB_per_launch": d["algorithmic_MB_per_launch"]}
             if roofline["traffic"]:   # what actually crossed the HBM interface, as a rate
                 roofline["hbm_GBs_from_pmc"] = roofline["traffic"] / 1e9 / (d["avg_ms"] / 1e3)
+        # this rank's rays over the time of the kernels that cast them (InitialTrace + TraceRays) only
+        trav_ms = sum(v["avg_ms"] * v["launches_per_frame"] for k, v in kernels.items()
+                      if k in ("primary", "candidates", "trace_rays", "ris_primary", "ris_trace_rays"))
+        trav_rate = rays_local / args.steps / 1e6 / (trav_ms / 1e3) if trav_ms > 0 else None
         out = {
             "metric": "Mrays/s (primary+shadow) " + ("RIS DL" if ris else "ReSTIR DL") + ", 80kScene 1080p",
             "value": rays_total / 1e6 / dt_max, "unit": "Mrays/s", "n_gpus": world, "steps": args.steps,
@@ -284,6 +288,7 @@ def main():
                        "parallelism": f"row-bands x{world} ({args.exchange} halo exchange)" if world > 1 else "single GPU",
                        "rays_per_frame": rays_total / args.steps},
             "roofline": roofline, "kernels": kernels,
+            "traversal_kernels_Mrays_per_s": trav_rate,
             "kernel_timing": f"HIP events on the library's stream: '{dominant}' around every launch of the timed region, "
                              f"the other kernels in {n_breakdown} untimed frames after it",
         }
