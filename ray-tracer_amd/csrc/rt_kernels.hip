@@ -545,6 +545,57 @@ DEV Reservoir loadReservoir(const Recs& rc, int64_t i) {
     const float4* q = rc.q + i * 4;
     return unpackReservoir(q[0], q[1], q[2], q[3]);
 }
+
+// A wave reading or writing the 64-byte reservoir records of ITS OWN 8x8 tile: one lane per record would touch 32
+// cache lines per 16-byte instruction (records are 64 bytes apart), so four adjacent lanes move the four quarters of
+// one record - every instruction covers two image rows of the tile as two runs of 512 contiguous bytes - and the wave
+// transposes through LDS (`stage`: 64 records of 5 float4, the fifth is padding against bank conflicts).
+// `mask` = lanes whose pixel takes part; x0, y0 = the tile's first pixel.
+constexpr int COOP_ROW = 5;
+DEV void waveFenceLds() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+DEV Reservoir coopLoadReservoir(const KParams& P, const Recs& rc, int x0, int y0, unsigned long long mask, float4* stage) {
+    const int lane = (int)(threadIdx.x & 63), col = (lane & 31) >> 2, piece = lane & 3;
+    #pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const int row = 2 * k + (lane >> 5), owner = row * 8 + col;
+        if ((mask >> owner) & 1ull) {
+            const int64_t i = (int64_t)((uint32_t)P.ResX * (uint32_t)(y0 + row) + (uint32_t)(x0 + col));
+            stage[owner * COOP_ROW + piece] = rc.q[i * 4 + piece];
+        }
+    }
+    waveFenceLds();
+    Reservoir r = emptyReservoir();
+    if ((mask >> lane) & 1ull) {
+        const float4* q = stage + lane * COOP_ROW;
+        r = unpackReservoir(q[0], q[1], q[2], q[3]);
+    }
+    waveFenceLds();
+    return r;
+}
+DEV void coopStoreReservoir(const KParams& P, const Recs& rc, int x0, int y0, unsigned long long mask, float4* stage, const Reservoir& r) {
+    const int lane = (int)(threadIdx.x & 63), col = (lane & 31) >> 2, piece = lane & 3;
+    if ((mask >> lane) & 1ull) {
+        float4* q = stage + lane * COOP_ROW;
+        q[0] = make_float4(r.dir.x, r.dir.y, r.dir.z, r.chosenWeight);
+        q[1] = make_float4(r.hitPoint.x, r.hitPoint.y, r.hitPoint.z, r.totWeights);
+        q[2] = make_float4(r.normal.x, r.normal.y, r.normal.z, r.totCandidates);
+        q[3] = make_float4(r.brdf, 0.0f, 0.0f, 0.0f);
+    }
+    waveFenceLds();
+    #pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const int row = 2 * k + (lane >> 5), owner = row * 8 + col;
+        if ((mask >> owner) & 1ull) {
+            const int64_t i = (int64_t)((uint32_t)P.ResX * (uint32_t)(y0 + row) + (uint32_t)(x0 + col));
+            rc.q[i * 4 + piece] = stage[owner * COOP_ROW + piece];
+        }
+    }
+    waveFenceLds();
+}
 DEV float depthAt(const KParams& P, int x, int y) {
     if (x < 0 || y < 0 || x >= P.ResX || y >= P.ResY) return 0.0f;
     return P.depth.r[(int64_t)y * P.ResX + x];
@@ -751,40 +802,49 @@ __global__ __launch_bounds__(256, RT_MIN_WAVES) void k_candidates(const KParams 
 // TemporalReuse (RS:586-641)
 // =====================================================================================================
 __global__ __launch_bounds__(256) void k_temporal(const KParams P) {
+    __shared__ float4 stageAll[WAVES_PER_BLOCK * 64 * COOP_ROW];
+    float4* stage = stageAll + (threadIdx.x >> 6) * 64 * COOP_ROW;
     const Pixel px = pixelOfThread(P);
     bool active = px.active && P.FrameCount != 0;
     if (active) active = depthAt(P, px.x, px.y) != INF();
-    if (active) {
+    const unsigned long long mask = __builtin_amdgcn_ballot_w64(active);
+    if (mask != 0) {  // wave-uniform: the record moves below are made by the whole wave
+        const int lane = (int)(threadIdx.x & 63);
+        const int x0 = px.x - (lane & 7), y0 = px.y - (lane >> 3);
         const uint32_t idx = (uint32_t)px.x, idy = (uint32_t)px.y;
         uint32_t state = idy * (uint32_t)P.ResX + idx + P.FrameRand;
         const uint32_t pixelIndex = (uint32_t)P.ResX * idy + idx;
-        v2 uv = {(float)idx / (float)P.ResX, (float)idy / (float)P.ResY};
-        v3 worldFocalPos = GetFocalPos(P, uv);
-        v2 lastUV = GetLastUV(P, worldFocalPos);
-        float dx = uv.x - lastUV.x, dy = uv.y - lastUV.y;
-        Reservoir thisFrame = loadReservoir(P.cand, pixelIndex);
-        if (__builtin_sqrtf(dx * dx + dy * dy) > P.TemporalPrecisionThreshold) {
-            storeReservoir(P.temporal, pixelIndex, thisFrame);
-        } else {
-            const int64_t i = (int64_t)idy * P.ResX + idx;
-            float4 a = P.hitA.rgba[i], b = P.hitB.rgba[i];
-            float movement = length(V3(a.x, a.y, a.z) - V3(b.x, b.y, b.z));
-            if (movement <= P.PixelMovementThreshold) {
-                Reservoir last = loadReservoir(P.temporal, pixelIndex);
-                float adjustedThis = thisFrame.totWeights * (1.0f - P.TemporalReuseWeight);
-                float adjustedLast = last.totWeights * P.TemporalReuseWeight;
-                float totWeights = adjustedThis + adjustedLast;
-                if (weightedRand(adjustedLast, totWeights, state)) {
-                    thisFrame.dir = last.dir;
-                    thisFrame.chosenWeight = last.chosenWeight;
-                    thisFrame.hitPoint = last.hitPoint;
+        Reservoir thisFrame = coopLoadReservoir(P, P.cand, x0, y0, mask, stage);
+        bool storeCand = false;
+        if (active) {
+            v2 uv = {(float)idx / (float)P.ResX, (float)idy / (float)P.ResY};
+            v3 worldFocalPos = GetFocalPos(P, uv);
+            v2 lastUV = GetLastUV(P, worldFocalPos);
+            float dx = uv.x - lastUV.x, dy = uv.y - lastUV.y;
+            if (__builtin_sqrtf(dx * dx + dy * dy) > P.TemporalPrecisionThreshold) {
+                storeReservoir(P.temporal, pixelIndex, thisFrame);
+            } else {
+                const int64_t i = (int64_t)idy * P.ResX + idx;
+                float4 a = P.hitA.rgba[i], b = P.hitB.rgba[i];
+                float movement = length(V3(a.x, a.y, a.z) - V3(b.x, b.y, b.z));
+                if (movement <= P.PixelMovementThreshold) {
+                    Reservoir last = loadReservoir(P.temporal, pixelIndex);
+                    float adjustedThis = thisFrame.totWeights * (1.0f - P.TemporalReuseWeight);
+                    float adjustedLast = last.totWeights * P.TemporalReuseWeight;
+                    float totWeights = adjustedThis + adjustedLast;
+                    if (weightedRand(adjustedLast, totWeights, state)) {
+                        thisFrame.dir = last.dir;
+                        thisFrame.chosenWeight = last.chosenWeight;
+                        thisFrame.hitPoint = last.hitPoint;
+                    }
+                    thisFrame.totWeights = avg(thisFrame.totWeights * (1.0f - P.TemporalReuseWeight), last.totWeights * P.TemporalReuseWeight);
+                    thisFrame.totCandidates = avg(thisFrame.totCandidates * (1.0f - P.TemporalReuseWeight), last.totCandidates * P.TemporalReuseWeight);
                 }
-                thisFrame.totWeights = avg(thisFrame.totWeights * (1.0f - P.TemporalReuseWeight), last.totWeights * P.TemporalReuseWeight);
-                thisFrame.totCandidates = avg(thisFrame.totCandidates * (1.0f - P.TemporalReuseWeight), last.totCandidates * P.TemporalReuseWeight);
+                storeCand = true;
+                storeReservoir(P.temporal, pixelIndex, thisFrame);
             }
-            storeReservoir(P.cand, pixelIndex, thisFrame);
-            storeReservoir(P.temporal, pixelIndex, thisFrame);
         }
+        coopStoreReservoir(P, P.cand, x0, y0, __builtin_amdgcn_ballot_w64(storeCand), stage, thisFrame);
     }
     if (P.stats && P.statsLevel >= 2) waveAdd(P.stats + ST_ACTIVE, active ? 1u : 0u);
 }
@@ -793,18 +853,23 @@ __global__ __launch_bounds__(256) void k_temporal(const KParams P) {
 // SpatialReusePass (RS:514-571)
 // =====================================================================================================
 __global__ __launch_bounds__(256) void k_spatial(const KParams P) {
+    __shared__ float4 stageAll[WAVES_PER_BLOCK * 64 * COOP_ROW];
+    float4* stage = stageAll + (threadIdx.x >> 6) * 64 * COOP_ROW;
     const Pixel px = pixelOfThread(P);
     bool active = px.active;
     if (active) active = depthAt(P, px.x, px.y) != INF();
     uint32_t neighbours = 0;
+    const unsigned long long mask = __builtin_amdgcn_ballot_w64(active);
+    const int x0 = px.x - (int)(threadIdx.x & 7), y0 = px.y - (int)((threadIdx.x & 63) >> 3);
+    const Recs& src = P.ReuseBufferCycle ? P.cand : P.candB;
+    const Recs& dstb = P.ReuseBufferCycle ? P.candB : P.cand;
+    Reservoir sp = emptyReservoir();
+    if (mask != 0) sp = coopLoadReservoir(P, src, x0, y0, mask, stage);  // the tile's own records, moved by the whole wave
     if (active) {
         const uint32_t idx = (uint32_t)px.x, idy = (uint32_t)px.y;
         uint32_t state = idy * (uint32_t)P.ResX + idx + P.FrameRand;
         const uint32_t pixelBaseIndex = (uint32_t)P.ResX * idy + idx;
-        const Recs& src = P.ReuseBufferCycle ? P.cand : P.candB;
-        const Recs& dstb = P.ReuseBufferCycle ? P.candB : P.cand;
-        const Reservoir base = loadReservoir(src, pixelBaseIndex);
-        Reservoir sp = base;
+        const Reservoir base = sp;
         for (uint32_t k = 0; k < P.TemporalCandidatesNum; k++) {
             int ox = rtdm::f2i((float)randIntSpan(-P.MaxOffset, P.MaxOffset, state));
             int oy = rtdm::f2i((float)randIntSpan(-P.MaxOffset, P.MaxOffset, state));
@@ -838,8 +903,8 @@ __global__ __launch_bounds__(256) void k_spatial(const KParams P) {
             sp.totWeights += cand.totWeights;
             sp.totCandidates += cand.totCandidates;
         }
-        storeReservoir(dstb, pixelBaseIndex, sp);
     }
+    if (mask != 0) coopStoreReservoir(P, dstb, x0, y0, mask, stage, sp);
     if (P.stats && P.statsLevel >= 2) { waveAdd(P.stats + ST_ACTIVE, active ? 1u : 0u); waveAdd(P.stats + ST_NEIGHBOURS, neighbours); }
 }
 
