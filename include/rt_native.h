@@ -42,7 +42,12 @@ typedef enum {
 typedef enum {
     RT_FORMAT_R32F = 1,      /* RenderTextureFormat.RFloat (Main.cs:359) */
     RT_FORMAT_RGBA32F = 2,   /* the 3- and 4-channel render targets and input textures, kept in fp32 */
-    RT_FORMAT_RGBA8_UNORM = 3 /* Texture2D RGBA32 inputs (ObjectHelper.cs:381); converted to fp32 on upload */
+    /* 8-bit UNORM.  As an input (Texture2D RGBA32, ObjectHelper.cs:381) the texels are uploaded as 4 bytes each.  As a
+     * render target (TextureHelper.cs:144-155 creates the 3- and 4-channel targets as RenderTextureFormat.Default)
+     * every kernel store clamps to [0, 1] and rounds to a multiple of 1/255, as the reference's targets do; this
+     * reaches the computation through TemporalReuse's hit-point movement test (ReSTIR_BVH_RayTracer.compute:613) and
+     * the running average of AccumulateFrames.  Storage and readback stay fp32 texels either way. */
+    RT_FORMAT_RGBA8_UNORM = 3
 } rt_format;
 
 /* ---- context ------------------------------------------------------------------------------------------- */

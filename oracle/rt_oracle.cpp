@@ -421,6 +421,14 @@ struct Ctx {
         float uvY = (ndcFocalPos.y / (2.0f * p.ViewSpaceDims[1])) + 0.5f;
         return {clampf(uvX, 0.0f, 1.0f), clampf(uvY, 0.0f, 1.0f)};
     }
+    // Store to a 3- or 4-channel render target.  With 8-bit targets (TextureHelper.cs:144-155: RenderTextureFormat.Default)
+    // the value is converted as D3D/Metal convert float to UNORM8: NaN -> 0, clamp to [0, 1], scale by 255, add 0.5,
+    // truncate; it is kept as the float the texture unit would return on the next load (n / 255).
+    static float toUnorm8(float x) { return (float)(int)(saturate(x) * 255.0f + 0.5f) / 255.0f; }
+    void storeRT(rt_float4* tex, int64_t px, rt_float4 v) const {
+        if (p.unorm8Targets) v = {toUnorm8(v.x), toUnorm8(v.y), toUnorm8(v.z), toUnorm8(v.w)};
+        tex[px] = v;
+    }
     float depthAt(int x, int y) const {  // RWTexture2D read, out of range -> 0
         if (x < 0 || y < 0 || x >= W || y >= H) return 0.0f;
         return f.DepthBuffer[(int64_t)y * W + x];
@@ -469,14 +477,13 @@ struct Ctx {
 
         bool badMaxBVHDepth = p.MaxBVHDepth > MAX_BVH_DEPTH;
         int64_t px = (int64_t)idy * W + idx;
-        f.DebugOverlay[px] = {debugData.triChecks / (float)p.DebugDataMaxValues[0],
-                              debugData.bvChecks / (float)p.DebugDataMaxValues[1], badMaxBVHDepth ? 1.0f : 0.0f, 0};
+        storeRT(f.DebugOverlay, px, {debugData.triChecks / (float)p.DebugDataMaxValues[0],
+                                     debugData.bvChecks / (float)p.DebugDataMaxValues[1], badMaxBVHDepth ? 1.0f : 0.0f, 0});
         f.DepthBuffer[px] = hitInfo.dst;
         f3 n = (hitInfo.normal + 1) * 0.5f;
-        f.NormalsBuffer[px] = {n.x, n.y, n.z, 0};
+        storeRT(f.NormalsBuffer, px, {n.x, n.y, n.z, 0});
         f3 firstHit = didHit ? hitInfo.hitPoint : F3(0, 0, 0);
-        if (p.FrameCount % 2 == 0) f.RayHitPointsA[px] = {firstHit.x, firstHit.y, firstHit.z, 0};
-        else f.RayHitPointsB[px] = {firstHit.x, firstHit.y, firstHit.z, 0};
+        storeRT(p.FrameCount % 2 == 0 ? f.RayHitPointsA : f.RayHitPointsB, px, {firstHit.x, firstHit.y, firstHit.z, 0});
 
         cnt.rays += 1 + (castShadow ? 1 : 0);
         cnt.pops += st.pops + shadowSt.pops; cnt.bvChecks += st.bvChecks + shadowSt.bvChecks;
@@ -547,6 +554,7 @@ struct Ctx {
         f2 lastFrameUV = GetLastUV(worldFocalPos);
         if (length(uv - lastFrameUV) > p.TemporalPrecisionThreshold) {
             f.TemporalFrameBuffer[pixelIndex] = f.Candidates[pixelIndex];
+            cnt.temporalCopies++;
             return;
         }
         // else offsetID = id.xy  (:605): the reprojected pixel is discarded, history is always same-pixel.
@@ -555,6 +563,7 @@ struct Ctx {
         rt_float4 a = f.RayHitPointsA[px], b = f.RayHitPointsB[px];
         float pixelHitPointMovement = length(F3(a.x, a.y, a.z) - F3(b.x, b.y, b.z));
         rt_reservoir thisFrameReservoir = f.Candidates[pixelIndex];
+        if (pixelHitPointMovement <= p.PixelMovementThreshold) cnt.temporalMerges++; else cnt.temporalRejects++;
         if (pixelHitPointMovement <= p.PixelMovementThreshold) {
             rt_reservoir lastFrameCandidate = ld(f.TemporalFrameBuffer, npx(), lastFramePixelIndex);
             float adjustedThisFrameWeight = thisFrameReservoir.totWeights * (1.0f - p.TemporalReuseWeight);
@@ -651,12 +660,12 @@ struct Ctx {
         f3 cdir = F3(candidateReservoir.dir);
         if (hitInfo.dst == INF) {
             f3 col = SampleEnvironmentMap(hitInfo.incomingDir);
-            f.Result[px] = {col.x, col.y, col.z, 0};
+            storeRT(f.Result, px, {col.x, col.y, col.z, 0});
             return;
         } else if ((cdir.x == 0 || cdir.y == 0 || cdir.z == 0) || dot(hitInfo.normal, cdir) < 0) {
             rt_material material = ld(s.Materials, s.nMaterials, hitInfo.materialIndex);
             f3 col = matCol(material, hitInfo.uv) * material.brightness / sqr(hitInfo.dst);
-            f.Result[px] = {col.x, col.y, col.z, 0};
+            storeRT(f.Result, px, {col.x, col.y, col.z, 0});
             return;
         }
         Ray ray;
@@ -670,7 +679,7 @@ struct Ctx {
         float correctionWeight = avgCandidateWeight / candidateReservoir.chosenWeight;
         traceInfo.indirectLight = traceInfo.indirectLight * correctionWeight;
         f3 combinedLight = traceInfo.directLight + (traceInfo.indirectLight / sqr(traceInfo.totTravelDst));
-        f.Result[px] = {combinedLight.x, combinedLight.y, combinedLight.z, 0};
+        storeRT(f.Result, px, {combinedLight.x, combinedLight.y, combinedLight.z, 0});
         if (f.records && rays) f.records[pixelIndex].bounceVisitHash = st.visitHash;
         cnt.rays += rays; cnt.pops += st.pops; cnt.bvChecks += st.bvChecks; cnt.objVisits += st.objVisits;
         cnt.triIters += st.triIters; cnt.triChecks += st.triChecks;
@@ -682,6 +691,7 @@ void addCounters(orc_counters* dst, const orc_counters& c) {
     dst->rays += c.rays; dst->pops += c.pops; dst->bvChecks += c.bvChecks; dst->objVisits += c.objVisits;
     dst->triIters += c.triIters; dst->triChecks += c.triChecks; dst->validNeighbours += c.validNeighbours;
     dst->activePixels += c.activePixels;
+    dst->temporalCopies += c.temporalCopies; dst->temporalMerges += c.temporalMerges; dst->temporalRejects += c.temporalRejects;
 }
 
 // Runs `fn(x, y, counters)` for every pixel of the band, in 8x8 tiles (the reference's thread groups,
@@ -777,6 +787,10 @@ int orc_accumulate_frames(const orc_params* p, orc_frame* f, int frameCount, int
         o.y = saturate(a.y * (1 - weight) + n.y * weight);
         o.z = saturate(a.z * (1 - weight) + n.z * weight);
         o.w = 0;
+        if (p->unorm8Targets) {
+            auto q = [](float x) { return (float)(int)(saturate(x) * 255.0f + 0.5f) / 255.0f; };
+            o = {q(o.x), q(o.y), q(o.z), 0};
+        }
         f->AccumulatedResult[i] = o;
     }
     return 0;

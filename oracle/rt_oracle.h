@@ -44,6 +44,11 @@ typedef struct {
     /* Image rows [row0, row1) to execute (a row band); row1 <= 0 means the whole image.  Pixel coordinates,
      * RNG seeds and buffer indices stay global, so a band computes exactly what the full frame would there. */
     int32_t row0, row1;
+    /* Non-zero: the 3- and 4-channel render targets (Result, AccumulatedResult, DebugOverlay, NormalsBuffer,
+     * RayHitPointsA/B) hold 8-bit UNORM texels as the reference's `new RenderTexture(w, h, 24)` does
+     * (TextureHelper.cs:144-155): every store clamps to [0, 1] and rounds to a multiple of 1/255.  The one place this
+     * feeds back into the computation is TemporalReuse's hit-point movement test (ReSTIR.compute:613). */
+    int32_t unorm8Targets;
 } orc_params;
 
 typedef struct {
@@ -80,6 +85,9 @@ typedef struct {
     uint64_t triChecks;   /* triangles passing the back-face pre-cull (debugData.triChecks) */
     uint64_t validNeighbours; /* SpatialReusePass: neighbours whose reservoir was fetched (:534) */
     uint64_t activePixels;    /* pixels not early-returned */
+    uint64_t temporalCopies;  /* TemporalReuse: pixels whose reprojection missed, copy-and-return (:600-604) */
+    uint64_t temporalMerges;  /* TemporalReuse: pixels merged with their history (:617 true) */
+    uint64_t temporalRejects; /* TemporalReuse: pixels whose hit point moved too far (:617 false) */
 } orc_counters;
 
 typedef struct {

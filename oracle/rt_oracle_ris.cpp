@@ -60,6 +60,14 @@ struct Ctx {
         H = p.Resolution[1];
     }
 
+    // Store to a render target; 8-bit UNORM targets (Main.cs:324-364: `new RenderTexture(w, h, 24)`) convert as D3D/Metal
+    // do (NaN -> 0, clamp, scale by 255, add 0.5, truncate) and keep the float the next load would return.
+    static float toUnorm8(float x) { return (float)(int)(saturate(x) * 255.0f + 0.5f) / 255.0f; }
+    void storeRT(rt_float4* tex, int64_t px, rt_float4 v) const {
+        if (p.unorm8Targets) v = {toUnorm8(v.x), toUnorm8(v.y), toUnorm8(v.z), toUnorm8(v.w)};
+        tex[px] = v;
+    }
+
     // RI:86-109
     static bool RayTriangleIntersect(const Ray& ray, const rt_ris_tri& tri, float& dstOut, f2& uvOut) {
         f3 edgeAB = F3(tri.vB) - F3(tri.vA);
@@ -294,10 +302,10 @@ struct Ctx {
         }
         int64_t px = (int64_t)idy * W + idx;
         f3 firstHit = didHit ? hitInfo.hitPoint : F3(0, 0, 0);
-        f.RayHitPoints[px] = {firstHit.x, firstHit.y, firstHit.z, 0};
+        storeRT(f.RayHitPoints, px, {firstHit.x, firstHit.y, firstHit.z, 0});
         bool badMaxBVHDepth = p.MaxBVHDepth >= (int)MAX_BVH_DEPTH;  // `>=` here, `>` in the ReSTIR project
-        f.DebugOverlay[px] = {debugData.triChecks / (float)p.DebugDataMaxValues[0],
-                              debugData.bvChecks / (float)p.DebugDataMaxValues[1], badMaxBVHDepth ? 1.0f : 0.0f, 0};
+        storeRT(f.DebugOverlay, px, {debugData.triChecks / (float)p.DebugDataMaxValues[0],
+                                     debugData.bvChecks / (float)p.DebugDataMaxValues[1], badMaxBVHDepth ? 1.0f : 0.0f, 0});
         if (f.records) {
             orc_trace_record& r = f.records[px];
             r.triIndex = st.triIndex; r.objIndex = st.objIndex; r.visitHash = st.visitHash;
@@ -372,12 +380,12 @@ struct Ctx {
         rt_float4 RISData = RayDirFromCandidates(rayIndex, state);
         f3 risDir = F3(RISData.x, RISData.y, RISData.z);
         if (hitInfo.dst == INF) {
-            f.Result[px] = {0, 0, 0, 0};
+            storeRT(f.Result, px, {0, 0, 0, 0});
             return;
         } else if (anyZero(risDir)) {
             rt_ris_material material = ld(s.Materials, s.nMaterials, hitInfo.materialIndex);
             f3 col = F3(material.color) * material.brightness / sqr(hitInfo.dst);
-            f.Result[px] = {col.x, col.y, col.z, 0};
+            storeRT(f.Result, px, {col.x, col.y, col.z, 0});
             return;
         }
         Ray ray;
@@ -389,7 +397,7 @@ struct Ctx {
         uint64_t rays = 0;
         for (int i = 0; i < p.RaysPerPixel; i++) combined = combined + Trace(ray, hitInfo, debugData, state, st, rays);
         combined = combined / correctionWeight;
-        f.Result[px] = {combined.x, combined.y, combined.z, 0};
+        storeRT(f.Result, px, {combined.x, combined.y, combined.z, 0});
         if (f.records && rays) f.records[px].bounceVisitHash = st.visitHash;
         cnt.rays += rays; cnt.pops += st.pops; cnt.bvChecks += st.bvChecks; cnt.objVisits += st.objVisits;
         cnt.triIters += st.triIters; cnt.triChecks += st.triChecks;

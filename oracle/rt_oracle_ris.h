@@ -33,6 +33,7 @@ typedef struct {
     float TotArea;
     int32_t SceneObjectReservoirTestsNum, TriReservoirTestsNum, CandidateReservoirTestsNum;
     int32_t row0, row1; /* row band, as in orc_params */
+    int32_t unorm8Targets; /* as in orc_params: Result, DebugOverlay, RayHitPoints hold 8-bit UNORM texels (Main.cs:324-364) */
 } orc_ris_params;
 
 typedef struct {

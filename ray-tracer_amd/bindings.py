@@ -101,7 +101,8 @@ class MainConfig(C.Structure):
                 ("SpatialNormalsAngleThreshold", C.c_float), ("SpatialBRDFThreshold", C.c_float),
                 ("VisibilityReuseThreshold", C.c_float), ("DoVisibilityReuse", C.c_int32),
                 ("DoWeightRecalc", C.c_int32), ("DoBRDF", C.c_int32), ("cameraPosition", C.c_float * 3),
-                ("cameraRotation", C.c_float * 4), ("frameRandBase", C.c_uint32), ("frameRandStep", C.c_uint32)]
+                ("cameraRotation", C.c_float * 4), ("frameRandBase", C.c_uint32), ("frameRandStep", C.c_uint32),
+                ("Unorm8RenderTargets", C.c_int32)]
 
 
 class RisConfig(C.Structure):
@@ -113,7 +114,7 @@ class RisConfig(C.Structure):
                 ("SceneObjectReservoirTestsNum", C.c_int32), ("TriReservoirTestsNum", C.c_int32),
                 ("CandidateReservoirTestsNum", C.c_int32), ("cameraPosition", C.c_float * 3),
                 ("cameraEulerDeg", C.c_float * 3), ("smoothness", C.c_float), ("frameRandBase", C.c_uint32),
-                ("frameRandStep", C.c_uint32)]
+                ("frameRandStep", C.c_uint32), ("Unorm8RenderTargets", C.c_int32)]
 
 
 class _RisSceneData(C.Structure):
@@ -195,7 +196,7 @@ def host_lib():
             "rth_main_update_per_frame": (ci, [vp]), "rth_main_run_restir_shader": (ci, [vp]),
             "rth_main_run_post_processing": (ci, [vp]), "rth_main_run_stage": (ci, [vp, ci]),
             "rth_main_run_spatial_pass": (ci, [vp, ci]), "rth_main_run_transfer": (ci, [vp]),
-            "rth_main_frame_count": (ci, [vp]), "rth_main_buffer": (vp, [vp, cs]), "rth_main_texture": (vp, [vp, cs]),
+            "rth_main_frame_count": (ci, [vp]), "rth_main_set_camera": (ci, [vp, fp, fp]), "rth_main_buffer": (vp, [vp, cs]), "rth_main_texture": (vp, [vp, cs]),
             "rth_main_shader": (vp, [vp, cs]),
             "rth_mg_band_bounds": (ci, [ci, ci, C.POINTER(ci)]), "rth_mg_halo_plan": (ci, [ci, ci, C.POINTER(ci), C.POINTER(ci)]),
             "rth_mg_unique_id": (ci, [C.c_char_p]), "rth_mg_create": (vp, [vp, ci, ci, C.POINTER(ci), C.c_char_p, C.c_char_p, ci]),
@@ -506,6 +507,11 @@ class Driver:
 
     def run_post_processing(self):
         self._check(self.lib.rth_main_run_post_processing(self.h), "run_post_processing")
+
+    def set_camera(self, position, rotation):
+        """transform.position / transform.rotation (quaternion x, y, z, w) from the next frame on."""
+        self._check(self.lib.rth_main_set_camera(self.h, _f3(position), (C.c_float * 4)(*[float(x) for x in rotation])),
+                    "set_camera")
 
     def shader(self, name="rt"):
         return self.lib.rth_main_shader(self.h, name.encode())

@@ -55,9 +55,10 @@ struct Recs {
 };
 
 struct Tex {
-    float4* rgba;  // RGBA32F textures
+    float4* rgba;  // RGBA textures (fp32 storage)
     float* r;      // R32F textures
     int w, h;
+    int unorm8;    // RT_FORMAT_RGBA8_UNORM render target: stores clamp to [0, 1] and round to a multiple of 1/255
 };
 
 // Mirror of the shader's constants (ReSTIR_BVH_RayTracer.compute:14-66,91-92), snapshotted at dispatch time from

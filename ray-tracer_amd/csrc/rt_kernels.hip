@@ -166,6 +166,14 @@ DEV v3 texLoad(const Tex& t, uint32_t x, uint32_t y) {
     float4 c = t.rgba[(int64_t)y * t.w + x];
     return V3(c.x, c.y, c.z);
 }
+// Store to a 3- or 4-channel render target.  The reference's are 8-bit (TextureHelper.cs:144-155); a target created
+// as RT_FORMAT_RGBA8_UNORM converts like D3D/Metal do - NaN -> 0, clamp to [0, 1], scale by 255, add 0.5, truncate -
+// and keeps the float the texture unit would return on the next load (n / 255).
+DEV float toUnorm8(float x) { return (float)rtdm::f2i(saturate(x) * 255.0f + 0.5f) / 255.0f; }
+DEV void storeRT(const Tex& t, int64_t i, float4 v) {
+    if (t.unorm8) v = make_float4(toUnorm8(v.x), toUnorm8(v.y), toUnorm8(v.z), toUnorm8(v.w));
+    t.rgba[i] = v;
+}
 // RS:94-100
 DEV v3 SampleTexture(v2 uv, uint32_t locX, uint32_t locY, uint32_t dimX, uint32_t dimY, const Tex& t) {
     uint32_t tx = locX + rtdm::f2u(uv.x * (float)dimX);
@@ -651,13 +659,13 @@ __global__ __launch_bounds__(256, RT_MIN_WAVES) void k_primary(const KParams P) 
         const int64_t i = (int64_t)idy * P.ResX + idx;
         storeHit(P, i, h);
         const bool badMaxBVHDepth = P.MaxBVHDepth > MAX_BVH_DEPTH;
-        P.debugOverlay.rgba[i] = make_float4(t.triChecks / (float)P.DebugMaxX, t.bvChecks / (float)P.DebugMaxY,
-                                             badMaxBVHDepth ? 1.0f : 0.0f, 0.0f);
+        storeRT(P.debugOverlay, i, make_float4(t.triChecks / (float)P.DebugMaxX, t.bvChecks / (float)P.DebugMaxY,
+                                               badMaxBVHDepth ? 1.0f : 0.0f, 0.0f));
         P.depth.r[i] = h.dst;
-        P.normals.rgba[i] = make_float4((h.normal.x + 1) * 0.5f, (h.normal.y + 1) * 0.5f, (h.normal.z + 1) * 0.5f, 0.0f);
+        storeRT(P.normals, i, make_float4((h.normal.x + 1) * 0.5f, (h.normal.y + 1) * 0.5f, (h.normal.z + 1) * 0.5f, 0.0f));
         v3 firstHit = didHit ? h.hitPoint : V3(0, 0, 0);
         float4 fh = make_float4(firstHit.x, firstHit.y, firstHit.z, 0.0f);
-        if (P.FrameCount % 2 == 0) P.hitA.rgba[i] = fh; else P.hitB.rgba[i] = fh;
+        storeRT(P.FrameCount % 2 == 0 ? P.hitA : P.hitB, i, fh);
         if (INSTR && P.records) {
             uint32_t* r = P.records + i * RECORD_DWORDS;
             r[0] = (uint32_t)t.tri; r[1] = (uint32_t)t.obj; r[2] = t.hash; r[3] = 0xffffffffu; r[4] = 0xffffffffu;
@@ -1033,7 +1041,7 @@ __global__ __launch_bounds__(256, 5) void k_trace_rays(const KParams P) {
             if (INSTR && P.records && rays) P.records[i * RECORD_DWORDS + 7] = hash;
         }
     }
-    if (px.active) P.result.rgba[(int64_t)px.y * P.ResX + px.x] = colour;
+    if (px.active) storeRT(P.result, (int64_t)px.y * P.ResX + px.x, colour);
     if (INSTR && P.waveProfile && P.waveProfileKernel == 2) writeWaveProfile(P, tStart, iters);
     if (P.stats) {
         waveAdd(P.stats + ST_RAYS, rays);
@@ -1057,7 +1065,7 @@ __global__ __launch_bounds__(256) void k_accumulate(const KParams P) {
     o.y = saturate(a.y * (1 - weight) + n.y * weight);
     o.z = saturate(a.z * (1 - weight) + n.z * weight);
     o.w = 0.0f;
-    P.accumulated.rgba[i] = o;
+    storeRT(P.accumulated, i, o);
 }
 
 // CalcTriNormals (PreCalc.compute:11-21,39-50)

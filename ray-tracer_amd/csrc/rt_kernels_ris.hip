@@ -105,10 +105,10 @@ __global__ __launch_bounds__(256, RT_MIN_WAVES) void k_ris_primary(const KParams
         }
         const int64_t i = (int64_t)idy * P.ResX + idx;
         v3 firstHit = didHit ? h.hitPoint : V3(0, 0, 0);
-        P.rayHitPoints.rgba[i] = make_float4(firstHit.x, firstHit.y, firstHit.z, 0.0f);
+        storeRT(P.rayHitPoints, i, make_float4(firstHit.x, firstHit.y, firstHit.z, 0.0f));
         const bool badMaxBVHDepth = P.risMaxBVHDepth >= (int32_t)MAX_BVH_DEPTH;  // `>=` (RI:410)
-        P.debugOverlay.rgba[i] = make_float4(t.triChecks / (float)P.DebugMaxX, t.bvChecks / (float)P.DebugMaxY,
-                                             badMaxBVHDepth ? 1.0f : 0.0f, 0.0f);
+        storeRT(P.debugOverlay, i, make_float4(t.triChecks / (float)P.DebugMaxX, t.bvChecks / (float)P.DebugMaxY,
+                                               badMaxBVHDepth ? 1.0f : 0.0f, 0.0f));
         if (INSTR && P.records) {
             uint32_t* r = P.records + i * RECORD_DWORDS;
             r[0] = (uint32_t)t.tri; r[1] = (uint32_t)t.obj; r[2] = t.hash; r[3] = 0xffffffffu; r[4] = 0xffffffffu;
@@ -276,11 +276,11 @@ __global__ __launch_bounds__(256, RT_MIN_WAVES) void k_ris_trace_rays(const KPar
         const v3 risDir = V3(chosen.x, chosen.y, chosen.z);
 
         if (first.dst == INF()) {
-            P.result.rgba[i] = make_float4(0, 0, 0, 0);
+            storeRT(P.result, i, make_float4(0, 0, 0, 0));
         } else if (anyZero(risDir)) {
             const rt_ris_material material = loadRisMaterial(P, first.materialIndex);
             v3 col = V3(material.color) * material.brightness / sqr(first.dst);
-            P.result.rgba[i] = make_float4(col.x, col.y, col.z, 0.0f);
+            storeRT(P.result, i, make_float4(col.x, col.y, col.z, 0.0f));
         } else {
             const float correctionWeight = risW * (float)P.RaysPerPixel;
             v3 combined = V3(0, 0, 0);
@@ -319,7 +319,7 @@ __global__ __launch_bounds__(256, RT_MIN_WAVES) void k_ris_trace_rays(const KPar
                 combined = combined + incomingLight;
             }
             combined = combined / correctionWeight;
-            P.result.rgba[i] = make_float4(combined.x, combined.y, combined.z, 0.0f);
+            storeRT(P.result, i, make_float4(combined.x, combined.y, combined.z, 0.0f));
             if (INSTR && P.records && rays) P.records[i * RECORD_DWORDS + 7] = hash;
         }
     }

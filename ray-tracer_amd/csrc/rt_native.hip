@@ -343,8 +343,6 @@ int prepareScene(rt_shader sh, int kernel, KParams& P, bool ris = false) {
     }
     P.sceneRootEntry = pr.sceneRootEntry;
     P.stackDepth = pr.stackDepth;
-    static const bool diagNoTraverse = getenv("RT_DIAG_NO_TRAVERSE") != nullptr;  // timing experiments only: every ray misses
-    if (diagNoTraverse) P.stackDepth = 0;
     return RT_OK;
 }
 
@@ -372,11 +370,12 @@ int needTex(rt_shader sh, int kernel, const char* name, bool r32, int resX, int 
     out.w = t->w; out.h = t->h;
     out.rgba = r32 ? nullptr : (float4*)t->dev;
     out.r = r32 ? (float*)t->dev : nullptr;
+    out.unorm8 = t->format == RT_FORMAT_RGBA8_UNORM;
     return RT_OK;
 }
 void optionalTex(rt_shader sh, int kernel, const char* name, Tex& out) {
     rt_texture t = boundTexture(sh, kernel, name);
-    out.rgba = nullptr; out.r = nullptr; out.w = out.h = 0;
+    out.rgba = nullptr; out.r = nullptr; out.w = out.h = 0; out.unorm8 = 0;
     if (t && t->format != RT_FORMAT_R32F) { out.rgba = (float4*)t->dev; out.w = t->w; out.h = t->h; }
 }
 
@@ -811,6 +810,7 @@ int dispatchPostProc(rt_shader sh, int kernel, int gx, int gy) {
     P.ResX = res->w; P.ResY = res->h;
     P.ppFrameCount = (int32_t)cWord(sh, "FrameCount");
     P.result.rgba = (float4*)res->dev; P.accumulated.rgba = (float4*)acc->dev;
+    P.accumulated.unorm8 = acc->format == RT_FORMAT_RGBA8_UNORM;
     unsigned blocks = 0;
     int rc = pixelGrid(ctx, P, gx, gy, &blocks);
     if (rc) return rc;

@@ -177,23 +177,25 @@ struct rth_main_s {
     // Main.cs:312-380
     void CreateTextures() {
         if (texturesCreated) return;
-        RTResultTexture = CreateTexture(ctx, Resolution(), RT_FORMAT_RGBA32F);
+        // TextureHelper.CreateTexture gives every 3- and 4-channel target the default 8-bit format (TextureHelper.cs:144-155)
+        const rt_format RT_FORMAT_TARGET = cfg.Unorm8RenderTargets ? RT_FORMAT_RGBA8_UNORM : RT_FORMAT_RGBA32F;
+        RTResultTexture = CreateTexture(ctx, Resolution(), RT_FORMAT_TARGET);
         rtShader.SetTexture(4, "Result", RTResultTexture);
         ppShader.SetTexture(0, "Result", RTResultTexture);
-        AccumulatedResultTexture = CreateTexture(ctx, Resolution(), RT_FORMAT_RGBA32F);
+        AccumulatedResultTexture = CreateTexture(ctx, Resolution(), RT_FORMAT_TARGET);
         ppShader.SetTexture(0, "AccumulatedResult", AccumulatedResultTexture);
-        DebugOverlayTexture = CreateTexture(ctx, Resolution(), RT_FORMAT_RGBA32F);
+        DebugOverlayTexture = CreateTexture(ctx, Resolution(), RT_FORMAT_TARGET);
         rtShader.SetTexture(0, "DebugOverlay", DebugOverlayTexture);
         rtShader.SetTexture(3, "DebugOverlay", DebugOverlayTexture);
-        RayHitPointATexture = CreateTexture(ctx, Resolution(), RT_FORMAT_RGBA32F);
+        RayHitPointATexture = CreateTexture(ctx, Resolution(), RT_FORMAT_TARGET);
         rtShader.SetTexture(0, "RayHitPointsA", RayHitPointATexture);
         rtShader.SetTexture(3, "RayHitPointsA", RayHitPointATexture);
-        RayHitPointBTexture = CreateTexture(ctx, Resolution(), RT_FORMAT_RGBA32F);
+        RayHitPointBTexture = CreateTexture(ctx, Resolution(), RT_FORMAT_TARGET);
         rtShader.SetTexture(0, "RayHitPointsB", RayHitPointBTexture);
         rtShader.SetTexture(3, "RayHitPointsB", RayHitPointBTexture);
         DepthBufferTexture = CreateTexture(ctx, Resolution(), RT_FORMAT_R32F);
         for (int k = 0; k < 4; k++) rtShader.SetTexture(k, "DepthBuffer", DepthBufferTexture);
-        NormalsBufferTexture = CreateTexture(ctx, Resolution(), RT_FORMAT_RGBA32F);
+        NormalsBufferTexture = CreateTexture(ctx, Resolution(), RT_FORMAT_TARGET);
         rtShader.SetTexture(0, "NormalsBuffer", NormalsBufferTexture);
         rtShader.SetTexture(1, "NormalsBuffer", NormalsBufferTexture);
         texturesCreated = true;
@@ -357,6 +359,12 @@ int rth_main_render_frame(rth_main m) {
     });
 }
 int rth_main_frame_count(rth_main m) { return m ? m->FrameCount : -1; }
+int rth_main_set_camera(rth_main m, const float position[3], const float rotation[4]) {
+    if (!m || !position || !rotation) return -1;
+    memcpy(m->cfg.cameraPosition, position, 12);
+    memcpy(m->cfg.cameraRotation, rotation, 16);
+    return 0;
+}
 
 rt_buffer rth_main_buffer(rth_main m, const char* name) {
     if (!m || !name) return nullptr;

@@ -160,14 +160,15 @@ struct rth_ris_main_s {
     // Main.cs:319-371
     void CreateTextures() {
         if (RTResultTexture.h) return;
-        RTResultTexture = CreateTexture(ctx, Resolution(), RT_FORMAT_RGBA32F);
+        const rt_format RT_FORMAT_TARGET = cfg.Unorm8RenderTargets ? RT_FORMAT_RGBA8_UNORM : RT_FORMAT_RGBA32F;  // Main.cs:324-364
+        RTResultTexture = CreateTexture(ctx, Resolution(), RT_FORMAT_TARGET);
         rtShader.SetTexture(1, "Result", RTResultTexture);
         ppShader.SetTexture(0, "Result", RTResultTexture);
-        AccumulatedResultTexture = CreateTexture(ctx, Resolution(), RT_FORMAT_RGBA32F);
+        AccumulatedResultTexture = CreateTexture(ctx, Resolution(), RT_FORMAT_TARGET);
         ppShader.SetTexture(0, "AccumulatedResult", AccumulatedResultTexture);
-        DebugOverlayTexture = CreateTexture(ctx, Resolution(), RT_FORMAT_RGBA32F);
+        DebugOverlayTexture = CreateTexture(ctx, Resolution(), RT_FORMAT_TARGET);
         rtShader.SetTexture(0, "DebugOverlay", DebugOverlayTexture);
-        RayHitPointTexture = CreateTexture(ctx, Resolution(), RT_FORMAT_RGBA32F);
+        RayHitPointTexture = CreateTexture(ctx, Resolution(), RT_FORMAT_TARGET);
         rtShader.SetTexture(0, "RayHitPoints", RayHitPointTexture);
     }
     void RunStage(int stage) {

@@ -133,6 +133,9 @@ typedef struct {
     /* FrameRand for frame k is (frameRandBase + frameRandStep*k) mod 999999; the reference draws
      * UnityEngine.Random.Range(0, 999999) (Main.cs:137), which is not reproducible. */
     uint32_t frameRandBase, frameRandStep;
+    /* 0: the 3- and 4-channel render targets are created as fp32 (results comparable to full precision);
+     * 1: as RT_FORMAT_RGBA8_UNORM, the format TextureHelper.CreateTexture gives them (TextureHelper.cs:144-155). */
+    int32_t Unorm8RenderTargets;
 } rth_main_config;
 
 void rth_main_default_config(rth_main_config* cfg); /* values of the committed Unity scene (Ray Tracer.unity:622-652) */
@@ -159,6 +162,10 @@ int rth_main_run_stage(rth_main m, int stage);
 int rth_main_run_spatial_pass(rth_main m, int i);
 int rth_main_run_transfer(rth_main m);
 int rth_main_frame_count(rth_main m);
+/* Moves the camera (transform.position / transform.rotation, quaternion x,y,z,w): the next UpdatePerFrame pushes the
+ * new WorldSpaceCameraPos / CameraTransform and the previous frame's as LastWorldSpaceCameraPos /
+ * LastCameraTransformInverse, as SetCameraData does every frame (Main.cs:184-204). */
+int rth_main_set_camera(rth_main m, const float position[3], const float rotation[4]);
 
 /* Named access to the driver's buffers and textures ("Candidates", "CandidatesB", "TemporalFrameBuffer",
  * "HitInfos", "Triangles", ...; "Result", "AccumulatedResult", "DebugOverlay", "DepthBuffer", "NormalsBuffer",
@@ -217,6 +224,7 @@ typedef struct {
     float cameraEulerDeg[3]; /* transform.rotation.eulerAngles (Main.cs:190) */
     float smoothness;        /* Material2.smoothness of every material */
     uint32_t frameRandBase, frameRandStep; /* as in rth_main_config */
+    int32_t Unorm8RenderTargets; /* 1: render targets as `new RenderTexture(w, h, 24)` makes them (Main.cs:324-364): 8-bit UNORM */
 } rth_ris_config;
 
 /* CameraTransform as Main.SetCameraOrientationAndTransform builds it from the Euler angles (Main.cs:189-211), column-major. */

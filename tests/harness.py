@@ -33,7 +33,8 @@ class OrcParams(C.Structure):
                 ("PixelMovementThreshold", C.c_float), ("TemporalPrecisionThreshold", C.c_float),
                 ("EmittingObjectsNum", C.c_uint32), ("TextureAtlasDimsRaw", C.c_uint32 * 2),
                 ("EnvironmentMapTexDimsRaw", C.c_uint32 * 2), ("kw_VIS_REUSE", C.c_int32),
-                ("kw_WEIGHT_RECALC", C.c_int32), ("kw_BRDF", C.c_int32), ("row0", C.c_int32), ("row1", C.c_int32)]
+                ("kw_WEIGHT_RECALC", C.c_int32), ("kw_BRDF", C.c_int32), ("row0", C.c_int32), ("row1", C.c_int32),
+                ("unorm8Targets", C.c_int32)]
 
 
 class OrcScene(C.Structure):
@@ -47,7 +48,8 @@ class OrcScene(C.Structure):
 
 class OrcCounters(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in ("rays", "pops", "bvChecks", "objVisits", "triIters", "triChecks",
-                                          "validNeighbours", "activePixels")]
+                                          "validNeighbours", "activePixels", "temporalCopies", "temporalMerges",
+                                          "temporalRejects")]
 
     def as_dict(self):
         return {n: int(getattr(self, n)) for n, _ in self._fields_}
@@ -158,16 +160,11 @@ class OracleRenderer:
         host.rth_view_space_dims(cfg.fieldOfView, cfg.Resolution[0], cfg.Resolution[1], vsd)
         p.ViewSpaceDims[0], p.ViewSpaceDims[1] = vsd[0], vsd[1]
         p.DefocusStrength, p.FocalPlaneFactor = cfg.DefocusStrength, cfg.FocalPlaneFactor
-        t, ti = (C.c_float * 16)(), (C.c_float * 16)()
-        host.rth_camera_matrices(cfg.cameraPosition, cfg.cameraRotation, t, ti)
-        ct = mat3_rowmajor_from_colmajor4(list(t))
-        cti = mat3_rowmajor_from_colmajor4(list(ti))
-        for i in range(3):
-            p.WorldSpaceCameraPos[i] = cfg.cameraPosition[i]
-            p.LastWorldSpaceCameraPos[i] = cfg.cameraPosition[i]
-        for i in range(9):
-            p.CameraTransform[i] = float(ct[i])
-            p.LastCameraTransformInverse[i] = float(cti[i])
+        # Main.Start (Main.cs:105-115) runs SetCameraData before the first frame: "last" starts as the initial camera
+        self.camera = ([float(x) for x in cfg.cameraPosition], [float(x) for x in cfg.cameraRotation])
+        self.last_camera = self.camera
+        self._set_camera_data()
+        p.unorm8Targets = cfg.Unorm8RenderTargets
         p.DebugDataMaxValues[0], p.DebugDataMaxValues[1] = cfg.DebugMaxTriChecks, cfg.DebugMaxBVChecks
         p.SceneObjectReservoirTestsNum, p.TriReservoirTestsNum = cfg.SceneObjectReservoirTestsNum, cfg.TriReservoirTestsNum
         p.TemporalCandidatesNum = cfg.TemporalCandidatesNum
@@ -184,6 +181,27 @@ class OracleRenderer:
     def set_band(self, row0, row1):
         self.p.row0, self.p.row1 = row0, row1
 
+    def set_camera(self, position, rotation):
+        """transform.position / transform.rotation from the next frame on."""
+        self.camera = ([float(x) for x in position], [float(x) for x in rotation])
+
+    def _set_camera_data(self):
+        """Main.SetCameraData (Main.cs:184-204): this frame's camera, and the previous frame's as Last*."""
+        host, p = rt.host_lib(), self.p
+        f3, f4 = C.c_float * 3, C.c_float * 4
+        t, ti, lt, lti = ((C.c_float * 16)() for _ in range(4))
+        host.rth_camera_matrices(f3(*self.camera[0]), f4(*self.camera[1]), t, ti)
+        host.rth_camera_matrices(f3(*self.last_camera[0]), f4(*self.last_camera[1]), lt, lti)
+        ct = mat3_rowmajor_from_colmajor4(list(t))
+        cti = mat3_rowmajor_from_colmajor4(list(lti))
+        for i in range(3):
+            p.WorldSpaceCameraPos[i] = self.camera[0][i]
+            p.LastWorldSpaceCameraPos[i] = self.last_camera[0][i]
+        for i in range(9):
+            p.CameraTransform[i] = float(ct[i])
+            p.LastCameraTransformInverse[i] = float(cti[i])
+        self.last_camera = self.camera
+
     # ---- Main.cs sequence ----
     def update_per_frame(self):
         cfg = self.cfg
@@ -192,6 +210,7 @@ class OracleRenderer:
         self.p.FrameCount = self.FrameCount
         self.pp_frame_count = self.FrameCount
         self.FrameCount += 1
+        self._set_camera_data()
 
     def _run(self, fn):
         rc = fn(C.byref(self.s), C.byref(self.p), C.byref(self.f), self.threads)
@@ -267,7 +286,8 @@ class OrcRisParams(C.Structure):
                 ("SceneObjectCandidatesNum", C.c_int32), ("TriCandidatesNum", C.c_int32),
                 ("TotCandidatesNum", C.c_int32), ("EmittingObjectsNum", C.c_int32), ("TotArea", C.c_float),
                 ("SceneObjectReservoirTestsNum", C.c_int32), ("TriReservoirTestsNum", C.c_int32),
-                ("CandidateReservoirTestsNum", C.c_int32), ("row0", C.c_int32), ("row1", C.c_int32)]
+                ("CandidateReservoirTestsNum", C.c_int32), ("row0", C.c_int32), ("row1", C.c_int32),
+                ("unorm8Targets", C.c_int32)]
 
 
 class OrcRisScene(C.Structure):
@@ -361,6 +381,7 @@ class RisOracleRenderer:
         p.SceneObjectReservoirTestsNum, p.TriReservoirTestsNum = cfg.SceneObjectReservoirTestsNum, cfg.TriReservoirTestsNum
         p.CandidateReservoirTestsNum = cfg.CandidateReservoirTestsNum
         p.row0, p.row1 = row0, row1
+        p.unorm8Targets = cfg.Unorm8RenderTargets
         s = self.s = OrcRisScene()
         s.BVs, s.nBVs = a["BVs"].ctypes.data, len(a["BVs"])
         s.SceneObjects, s.nSceneObjects = a["SceneObjects"].ctypes.data, len(a["SceneObjects"])
@@ -398,6 +419,7 @@ class RisOracleRenderer:
         p = OrcParams()
         p.Resolution[0], p.Resolution[1] = self.W, self.H
         p.row0, p.row1 = self.p.row0, self.p.row1
+        p.unorm8Targets = self.p.unorm8Targets
         f = OrcFrame()
         f.Result, f.AccumulatedResult = self.tex["Result"].ctypes.data, self.tex["AccumulatedResult"].ctypes.data
         assert self.lib.orc_accumulate_frames(C.byref(p), C.byref(f), self.pp_frame_count, self.threads) == 0
