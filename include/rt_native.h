@@ -36,7 +36,8 @@ typedef enum {
     RT_ERR_OUT_OF_MEMORY = -3,
     RT_ERR_UNBOUND = -4,       /* a dispatch needs a buffer/texture/constant that was never set */
     RT_ERR_BAD_SCENE = -5,     /* scene buffers failed validation (index out of range, BVH too deep, cycle) */
-    RT_ERR_LIMIT = -6          /* a size exceeds a documented limit of an entry point */
+    RT_ERR_LIMIT = -6,         /* a size exceeds a documented limit of an entry point */
+    RT_ERR_NOT_PREPARED = -7   /* rt_dispatch_no_alloc only: the dispatch would have to allocate device memory */
 } rt_status;
 
 typedef enum {
@@ -86,6 +87,24 @@ int rt_find_kernel(rt_shader sh, const char* name);
 /* ComputeShader.Dispatch (ComputeHelper.cs:16,23).  Thread-group sizes are fixed per kernel as in
  * ComputeShaders/Constants.hlsl:7-9 (8x8x1 for the tracer and post-process kernels, 256x1x1 for PreCalc). */
 int rt_dispatch(rt_shader sh, int kernel, int groups_x, int groups_y, int groups_z);
+
+/* rt_dispatch for callers that cannot allocate device memory (a frame loop under HIP graph capture, a serving loop
+ * or harness that forbids hipMalloc).  No counterpart in the reference.  Same arguments, same kernels and bit-identical
+ * results, but the call makes no hipMalloc / hipFree or any other allocating call: what rt_dispatch allocates lazily
+ * and caches - the workgroup-to-image-block table of the launch and the per-tile hit counts InitialTrace ranks it by -
+ * lives instead in a fixed 1.25 MiB device array that the library holds on every GPU it runs on until the process
+ * ends, and is rebuilt on the stream by every call (two small extra launches).
+ *  - Limit: the launch may cover at most 4096 regions of 64x64 pixels (e.g. 4096x4096 pixels, or the rows of a row
+ *    band); beyond it the call fails with RT_ERR_LIMIT and launches nothing.
+ *  - What cannot be done without allocating is refused with RT_ERR_NOT_PREPARED: scene buffers whose traversal arrays
+ *    are not built yet (rt_dispatch builds them at the first dispatch of a traversal kernel after a scene upload) and
+ *    per-pixel buffers not yet in the library's internal layout (the first rt_dispatch that binds them converts
+ *    them).  Run one frame with rt_dispatch first; rt_buffer_set_data on a reservoir or HitInfos buffer puts it
+ *    back into the ABI layout (rt_buffer_get_data does not).
+ *  - Launches are not timed (rt_profile_enable is ignored for them); work counters are kept as usual.
+ *  - All contexts on one GPU share the array: calls that overlap in time on one GPU (different contexts, hence
+ *    different streams) race on it.  Calls on one context are ordered by its stream. */
+int rt_dispatch_no_alloc(rt_shader sh, int kernel, int groups_x, int groups_y, int groups_z);
 
 /* ComputeShader.EnableKeyword / DisableKeyword (Main.cs:252-257): "VIS_REUSE", "WEIGHT_RECALC", "BRDF".
  * Unknown keywords are ignored, as Unity does. */

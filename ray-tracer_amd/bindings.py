@@ -66,6 +66,7 @@ def native_lib():
             "rt_last_error": (cs, [vp]), "rt_stream": (vp, [vp]), "rt_set_row_band": (ci, [vp, ci, ci]),
             "rt_shader_open": (ci, [vp, cs, C.POINTER(vp)]), "rt_shader_close": (None, [vp]),
             "rt_find_kernel": (ci, [vp, cs]), "rt_dispatch": (ci, [vp, ci, ci, ci, ci]),
+            "rt_dispatch_no_alloc": (ci, [vp, ci, ci, ci, ci]),
             "rt_enable_keyword": (ci, [vp, cs]), "rt_disable_keyword": (ci, [vp, cs]),
             "rt_set_int": (ci, [vp, cs, ci]), "rt_set_float": (ci, [vp, cs, cf]), "rt_set_bool": (ci, [vp, cs, ci]),
             "rt_set_ints": (ci, [vp, cs, C.POINTER(ci), ci]), "rt_set_vector": (ci, [vp, cs, C.POINTER(cf)]),

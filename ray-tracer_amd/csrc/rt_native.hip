@@ -32,6 +32,15 @@ const char* const IK_NAMES[IK_COUNT] = {"primary", "candidates", "temporal", "sp
 
 }  // namespace
 
+// Scratch of rt_dispatch_no_alloc: the workgroup -> block table of one launch (TABLE words) followed by the per-wave
+// hit counts the table is ranked by (COST words).  File scope, so it exists once per GPU for the life of the process;
+// `scratch` itself is only a host-side handle: the device address is taken once per device with hipGetSymbolAddress
+// (rt_create) and every use below goes through that pointer.
+constexpr unsigned NOALLOC_MAX_REGIONS = ORDER_MAX_REGIONS;                                    // 64x64-pixel regions per launch
+constexpr size_t NOALLOC_TABLE_WORDS = (size_t)NOALLOC_MAX_REGIONS * RT_REGION * RT_REGION;    // one word per 16x16-pixel block
+constexpr size_t NOALLOC_COST_WORDS = NOALLOC_TABLE_WORDS * 4;                                 // one word per 8x8-pixel tile
+static __device__ __align__(256) uint32_t scratch[NOALLOC_TABLE_WORDS + NOALLOC_COST_WORDS];   // 1.25 MiB
+
 struct rt_ctx_s {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -44,6 +53,9 @@ struct rt_ctx_s {
     // per-wave hit counts in cost (null when the grid has more regions than that kernel sorts)
     struct BlockMap { int bx, by; uint32_t* dev; unsigned n; uint32_t* dyn; uint32_t* cost; unsigned nDyn; bool dynValid; unsigned age; };
     std::vector<BlockMap> blockMaps;  // one per band height in use (a multi-GPU host alternates between a few)
+    uint32_t* scratch = nullptr;  // this device's address of the file-scope `scratch` array
+    bool noAlloc = false;         // set for the duration of rt_dispatch_no_alloc
+    BlockMap noAllocMap = {};     // the table of the launch in flight when noAlloc is set (lives in `scratch`)
     // per-internal-kernel timing with HIP events on the context's stream
     bool timing = false;
     int timingOnly = -1;  // IK_* of the only kernel whose launches are bracketed by events, -1 = all
@@ -150,6 +162,9 @@ void launchToAos(rt_buffer b, void* dst) {
 int convertLayout(rt_buffer b, int target) {
     if (b->layout == target) return RT_OK;
     rt_ctx ctx = b->ctx;
+    if (ctx->noAlloc)
+        return fail(ctx, RT_ERR_NOT_PREPARED, "a per-pixel buffer is not in the layout this kernel keeps it in: converting it allocates; "
+                                              "dispatch the kernel once with rt_dispatch after creating or uploading the buffer");
     if (b->stride != 52) return fail(ctx, RT_ERR_INVALID_ARG, "buffer stride %d cannot hold a 52-byte per-pixel record", b->stride);
     if (b->layout != LAYOUT_AOS && target != LAYOUT_AOS) return fail(ctx, RT_ERR_INVALID_ARG, "buffer is bound as two different record types");
     void* tmp = nullptr;
@@ -263,6 +278,9 @@ int prepareScene(rt_shader sh, int kernel, KParams& P, bool ris = false) {
                        pr.vObjs == bObjs->version && pr.pBVs == bBVs->dev && pr.pTris == bTris->dev && pr.pVerts == bVerts->dev &&
                        pr.pObjs == bObjs->dev && pr.sceneStart == sceneStart;
     if (!fresh) {
+        if (ctx->noAlloc)
+            return fail(ctx, RT_ERR_NOT_PREPARED, "the traversal arrays of the bound scene buffers are not built: building them allocates; "
+                                                  "dispatch kernel %d once with rt_dispatch after uploading the scene", kernel);
         pr.valid = false;
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
         std::vector<rt_bv> bvs((size_t)bBVs->count);
@@ -292,6 +310,10 @@ int prepareScene(rt_shader sh, int kernel, KParams& P, bool ris = false) {
             if (d > maxMeshDepth) maxMeshDepth = d;
         }
         pr.stackDepth = sceneDepth + maxMeshDepth + 2;
+        // the per-lane stack lives in LDS: 4 waves x 64 lanes x 4 bytes per entry, within the 64 KiB a workgroup may ask for
+        if ((size_t)WAVES_PER_BLOCK * pr.stackDepth * 64 * 4 > 65536)
+            return fail(ctx, RT_ERR_LIMIT, "BVH too deep: scene BVH of %d levels + mesh BVH of %d levels need a traversal stack of %d entries, the limit is %d",
+                        sceneDepth, maxMeshDepth, pr.stackDepth, 65536 / (WAVES_PER_BLOCK * 64 * 4));
 
         auto ensure = [&](void** p, size_t* have, size_t need) -> int {
             if (*have >= need && *p) return RT_OK;
@@ -476,6 +498,27 @@ int pixelGrid(rt_ctx ctx, KParams& P, int gx, int gy, unsigned* blocks, rt_ctx_s
     static const bool reorder = [] { const char* e = getenv("RT_BLOCK_ORDER"); return e ? atoi(e) != 0 : true; }();
     P.blocksX = (int)bx;
     P.blockCost = nullptr;
+    if (ctx->noAlloc) {
+        // The table is built in the file-scope scratch, on the stream, for this launch alone: hit counts cleared, then
+        // k_order_blocks on all-zero counts deals the regions to the XCDs in some order (any order renders the same image).
+        const unsigned regions = ((bx + RT_REGION - 1) / RT_REGION) * ((by + RT_REGION - 1) / RT_REGION);
+        if (regions > NOALLOC_MAX_REGIONS)
+            return fail(ctx, RT_ERR_LIMIT, "rt_dispatch_no_alloc: %u x %u pixels are %u regions of 64x64 pixels, the scratch table holds %u",
+                        bx * 16, by * 16, regions, NOALLOC_MAX_REGIONS);
+        rt_ctx_s::BlockMap& m = ctx->noAllocMap;
+        m.bx = (int)bx; m.by = (int)by;
+        m.dev = m.dyn = ctx->scratch;
+        m.cost = ctx->scratch + NOALLOC_TABLE_WORDS;
+        m.n = m.nDyn = (regions + 7) / 8 * (8 * RT_REGION * RT_REGION);
+        m.dynValid = false; m.age = 0;
+        HIP_TRY(ctx, hipMemsetAsync(m.cost, 0, (size_t)bx * by * 4 * sizeof(uint32_t), ctx->stream));
+        hipLaunchKernelGGL(k_order_blocks, dim3(1), dim3(1024), 0, ctx->stream, m.cost, m.bx, m.by, m.dyn, m.nDyn);
+        HIP_TRY(ctx, hipGetLastError());
+        P.blockMap = m.dev;
+        *blocks = m.n;
+        if (used) *used = &m;
+        return RT_OK;
+    }
     auto use = [&](rt_ctx_s::BlockMap& m) {
         P.blockMap = m.dynValid ? m.dyn : m.dev;
         *blocks = m.dynValid ? m.nDyn : m.n;
@@ -526,7 +569,7 @@ struct LaunchScope {
     LaunchScope(rt_ctx c, int k, KParams* P) : ctx(c), ik(k) {
         if (P) { P->stats = ctx->statsLevel > 0 ? ctx->statsDev + (size_t)k * STAT_SHARDS * 8 : nullptr; P->statsLevel = ctx->statsLevel; }
         ctx->launches[k]++;
-        if (!ctx->timing || (ctx->timingOnly >= 0 && ctx->timingOnly != k)) return;
+        if (!ctx->timing || ctx->noAlloc || (ctx->timingOnly >= 0 && ctx->timingOnly != k)) return;
         auto take = [&]() -> hipEvent_t {
             if (!ctx->freeEvents.empty()) { hipEvent_t e = ctx->freeEvents.back(); ctx->freeEvents.pop_back(); return e; }
             hipEvent_t e = nullptr;
@@ -840,6 +883,11 @@ int rt_create(int device_id, rt_ctx* out) {
         delete ctx;
         return RT_ERR_NO_DEVICE;
     }
+    // this device's copy of the file-scope scratch array (every GPU has its own, at its own address)
+    if (hipGetSymbolAddress((void**)&ctx->scratch, HIP_SYMBOL(scratch)) != hipSuccess || !ctx->scratch) {
+        rt_destroy(ctx);
+        return RT_ERR_NO_DEVICE;
+    }
     *out = ctx;
     return RT_OK;
 }
@@ -925,6 +973,15 @@ int rt_dispatch(rt_shader sh, int kernel, int gx, int gy, int gz) {
         case SH_POSTPROC: return dispatchPostProc(sh, kernel, gx, gy);
     }
     return fail(ctx, RT_ERR_INVALID_ARG, "shader kind %d cannot be dispatched", sh->kind);
+}
+
+int rt_dispatch_no_alloc(rt_shader sh, int kernel, int gx, int gy, int gz) {
+    if (!sh) return RT_ERR_INVALID_ARG;
+    rt_ctx ctx = sh->ctx;
+    ctx->noAlloc = true;  // every path below that would allocate (or free) device memory returns an error instead
+    int rc = rt_dispatch(sh, kernel, gx, gy, gz);
+    ctx->noAlloc = false;
+    return rc;
 }
 
 int rt_enable_keyword(rt_shader sh, const char* kw) {
