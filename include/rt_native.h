@@ -146,6 +146,10 @@ int rt_buffer_set_data(rt_buffer buf, const void* src, size_t bytes);
 /* ComputeBuffer.GetData.  Waits for enqueued work, then copies `bytes` from the start of the buffer, always in
  * the reference's array-of-structures layout, whatever layout the library keeps internally. */
 int rt_buffer_get_data(rt_buffer buf, void* dst, size_t bytes);
+/* ComputeBuffer.GetData(Array data, int managedBufferStartIndex, int computeBufferStartIndex, int count) — Unity's
+ * partial readback: elements [first, first + count) in the reference's layout (the reference itself only reads whole
+ * buffers; tests at 4K read the rows they compare). */
+int rt_buffer_get_range(rt_buffer buf, void* dst, int64_t first, int64_t count);
 /* ComputeBuffer.Release (ComputeHelper.cs:203-214); NULL is ignored. */
 void rt_buffer_release(rt_buffer buf);
 int64_t rt_buffer_count(rt_buffer buf);
@@ -160,6 +164,8 @@ int rt_texture_create(rt_ctx ctx, int width, int height, rt_format format, rt_te
 int rt_texture_set_data(rt_texture tex, const void* src, size_t bytes);
 /* Readback (RenderTexture -> Texture2D.ReadPixels, Main.cs:544-557): fp32 texels (1 or 4 floats per texel). */
 int rt_texture_get_data(rt_texture tex, void* dst, size_t bytes);
+/* Rows [row0, row1) only (Texture2D.ReadPixels with a source rectangle), fp32 texels. */
+int rt_texture_get_rows(rt_texture tex, void* dst, int row0, int row1);
 void rt_texture_release(rt_texture tex);
 
 /* ---- multi-GPU row access (no counterpart in the reference) ----------------------------------------------- */

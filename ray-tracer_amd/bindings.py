@@ -74,6 +74,7 @@ def native_lib():
             "rt_set_buffer": (ci, [vp, ci, cs, vp]), "rt_set_texture": (ci, [vp, ci, cs, vp]),
             "rt_buffer_create": (ci, [vp, C.c_int64, ci, C.POINTER(vp)]),
             "rt_buffer_set_data": (ci, [vp, vp, C.c_size_t]), "rt_buffer_get_data": (ci, [vp, vp, C.c_size_t]),
+            "rt_buffer_get_range": (ci, [vp, vp, C.c_int64, C.c_int64]), "rt_texture_get_rows": (ci, [vp, vp, ci, ci]),
             "rt_buffer_release": (None, [vp]), "rt_buffer_count": (C.c_int64, [vp]), "rt_buffer_stride": (ci, [vp]),
             "rt_texture_create": (ci, [vp, ci, ci, ci, C.POINTER(vp)]),
             "rt_texture_set_data": (ci, [vp, vp, C.c_size_t]), "rt_texture_get_data": (ci, [vp, vp, C.c_size_t]),
@@ -426,6 +427,17 @@ class RtContext:
         self.check(self.lib.rt_buffer_get_data(buf, out.ctypes.data, out.nbytes), "rt_buffer_get_data")
         return out
 
+    def get_buffer_range(self, buf, dtype, first, count):
+        out = np.empty(count, dtype=dtype)
+        self.check(self.lib.rt_buffer_get_range(buf, out.ctypes.data, first, count), "rt_buffer_get_range")
+        return out
+
+    def get_texture_rows(self, tex, w, row0, row1, channels):
+        n = row1 - row0
+        out = np.empty((n, w, channels) if channels > 1 else (n, w), dtype=np.float32)
+        self.check(self.lib.rt_texture_get_rows(tex, out.ctypes.data, row0, row1), "rt_texture_get_rows")
+        return out
+
     def create_texture(self, w, h, fmt):
         t = C.c_void_p()
         self.check(self.lib.rt_texture_create(self.h, w, h, fmt, C.byref(t)), "rt_texture_create")
@@ -538,6 +550,14 @@ class Driver:
     def texture(self, name):
         ch = 1 if name == "DepthBuffer" else 4
         return self.ctx.get_texture(self.texture_handle(name), self.W, self.H, ch)
+
+    def buffer_rows(self, name, row0, row1):
+        """Image rows [row0, row1) of a per-pixel buffer."""
+        return self.ctx.get_buffer_range(self.buffer_handle(name), DTYPES[self._BUF_DTYPE[name]], row0 * self.W,
+                                         (row1 - row0) * self.W)
+
+    def texture_rows(self, name, row0, row1):
+        return self.ctx.get_texture_rows(self.texture_handle(name), self.W, row0, row1, 1 if name == "DepthBuffer" else 4)
 
     def close(self):
         if self.h:

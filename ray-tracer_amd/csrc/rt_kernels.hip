@@ -1147,10 +1147,12 @@ __global__ void k_aos_to_planes(const float* aos, Planes pl, int kind) {
         pl.p3[i] = r[5];
     }
 }
-__global__ void k_planes_to_aos(Planes pl, float* aos, int kind) {
-    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= pl.count) return;
-    float* r = aos + i * 13;
+// The two *_to_aos kernels convert records [first, first + n) into `aos` (n records).
+__global__ void k_planes_to_aos(Planes pl, float* aos, int kind, int64_t first, int64_t n) {
+    int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    const int64_t i = first + j;
+    float* r = aos + j * 13;
     float4 a = pl.p0[i], b = pl.p1[i], c = pl.p2[i];
     float d = pl.p3[i];
     if (kind == 0) {
@@ -1175,11 +1177,11 @@ __global__ void k_aos_to_recs(const float* aos, Recs rc) {
     q[2] = make_float4(r[6], r[7], r[8], r[12]);
     q[3] = make_float4(r[9], 0.0f, 0.0f, 0.0f);
 }
-__global__ void k_recs_to_aos(Recs rc, float* aos) {
-    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= rc.count) return;
-    float* r = aos + i * 13;
-    const float4* q = rc.q + i * 4;
+__global__ void k_recs_to_aos(Recs rc, float* aos, int64_t first, int64_t n) {
+    int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    float* r = aos + j * 13;
+    const float4* q = rc.q + (first + j) * 4;
     float4 a = q[0], b = q[1], c = q[2], d = q[3];
     r[0] = a.x; r[1] = a.y; r[2] = a.z; r[10] = a.w;
     r[3] = b.x; r[4] = b.y; r[5] = b.z; r[11] = b.w;

@@ -152,10 +152,12 @@ Recs recsOf(rt_buffer b) {
 size_t layoutBytes(rt_buffer b, int layout) { return layout == LAYOUT_RESERVOIR_RECS ? (size_t)b->count * 64 : b->bytes; }
 
 // Enqueues the conversion of a 52-byte-stride buffer's contents into the ABI layout at `dst`.
-void launchToAos(rt_buffer b, void* dst) {
-    const int blocks = (int)((b->count + 255) / 256);
-    if (b->layout == LAYOUT_RESERVOIR_RECS) hipLaunchKernelGGL(k_recs_to_aos, dim3(blocks), dim3(256), 0, b->ctx->stream, recsOf(b), (float*)dst);
-    else hipLaunchKernelGGL(k_planes_to_aos, dim3(blocks), dim3(256), 0, b->ctx->stream, planesOf(b), (float*)dst, b->layout == LAYOUT_RESERVOIR_PLANES ? 0 : 1);
+void launchToAos(rt_buffer b, void* dst, int64_t first = 0, int64_t n = -1) {
+    if (n < 0) n = b->count - first;
+    if (n <= 0) return;
+    const int blocks = (int)((n + 255) / 256);
+    if (b->layout == LAYOUT_RESERVOIR_RECS) hipLaunchKernelGGL(k_recs_to_aos, dim3(blocks), dim3(256), 0, b->ctx->stream, recsOf(b), (float*)dst, first, n);
+    else hipLaunchKernelGGL(k_planes_to_aos, dim3(blocks), dim3(256), 0, b->ctx->stream, planesOf(b), (float*)dst, b->layout == LAYOUT_RESERVOIR_PLANES ? 0 : 1, first, n);
 }
 
 // Switches a 52-byte-stride buffer between the ABI's array-of-structures layout and an internal one.
@@ -179,8 +181,13 @@ int convertLayout(rt_buffer b, int target) {
     } else {
         hipLaunchKernelGGL(k_aos_to_planes, dim3(blocks), dim3(256), 0, ctx->stream, (const float*)b->dev, planesOf(&shadow), target == LAYOUT_RESERVOIR_PLANES ? 0 : 1);
     }
-    HIP_TRY(ctx, hipGetLastError());
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) {
+        hipError_t e2 = hipFree(tmp);
+        (void)e2;
+        return fail(ctx, RT_ERR_NO_DEVICE, "layout conversion failed: %s", hipGetErrorString(e));
+    }
     HIP_TRY(ctx, hipFree(b->dev));
     b->dev = tmp;
     b->layout = target;
@@ -1087,6 +1094,32 @@ int rt_buffer_get_data(rt_buffer b, void* dst, size_t bytes) {
     return RT_OK;
 }
 
+int rt_buffer_get_range(rt_buffer b, void* dst, int64_t first, int64_t count) {
+    if (!b || (!dst && count)) return RT_ERR_INVALID_ARG;
+    rt_ctx ctx = b->ctx;
+    if (first < 0 || count < 0 || first + count > b->count)
+        return fail(ctx, RT_ERR_INVALID_ARG, "elements [%lld, %lld) are outside a buffer of %lld", (long long)first, (long long)(first + count), (long long)b->count);
+    if (count == 0) return RT_OK;
+    int rc = useDevice(ctx);
+    if (rc) return rc;
+    const size_t bytes = (size_t)count * b->stride;
+    if (b->layout == LAYOUT_AOS) {
+        HIP_TRY(ctx, hipMemcpyAsync(dst, (const char*)b->dev + (size_t)first * b->stride, bytes, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        return RT_OK;
+    }
+    void* tmp = nullptr;
+    HIP_TRY(ctx, hipMalloc(&tmp, bytes));
+    launchToAos(b, tmp, first, count);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipMemcpyAsync(dst, tmp, bytes, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    hipError_t e2 = hipFree(tmp);
+    (void)e2;
+    if (e != hipSuccess) return fail(ctx, RT_ERR_NO_DEVICE, "buffer readback failed: %s", hipGetErrorString(e));
+    return RT_OK;
+}
+
 void rt_buffer_release(rt_buffer b) {
     if (!b) return;
     hipError_t e = hipSetDevice(b->ctx->device);
@@ -1156,6 +1189,19 @@ int rt_texture_get_data(rt_texture t, void* dst, size_t bytes) {
     int rc = useDevice(ctx);
     if (rc) return rc;
     HIP_TRY(ctx, hipMemcpyAsync(dst, t->dev, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return RT_OK;
+}
+
+int rt_texture_get_rows(rt_texture t, void* dst, int row0, int row1) {
+    if (!t || !dst) return RT_ERR_INVALID_ARG;
+    rt_ctx ctx = t->ctx;
+    if (row0 < 0 || row1 < row0 || row1 > t->h) return fail(ctx, RT_ERR_INVALID_ARG, "rows [%d,%d) are outside the texture", row0, row1);
+    if (row1 == row0) return RT_OK;
+    int rc = useDevice(ctx);
+    if (rc) return rc;
+    const size_t rowBytes = (size_t)t->w * (t->format == RT_FORMAT_R32F ? 4 : 16);
+    HIP_TRY(ctx, hipMemcpyAsync(dst, (const char*)t->dev + rowBytes * row0, rowBytes * (size_t)(row1 - row0), hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return RT_OK;
 }
