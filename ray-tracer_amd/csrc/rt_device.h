@@ -16,7 +16,8 @@ namespace rtn {
 // It holds what one traversal step needs — both children's boxes and both children's stack entries — so an
 // internal visit is ONE aligned 64-byte fetch instead of the reference's three dependent 32-byte BV fetches
 // (BVH_ReSTIR_DL/.../ReSTIR_BVH_RayTracer.compute:171,198-199).
-//   q0 = minA.xyz, maxA.x   q1 = maxA.yz, minB.xy   q2 = minB.z, maxB.xyz   q3 = entryA, entryB, 0, 0
+//   q0 = minA.xy, maxA.xy   q1 = minB.xy, maxB.xy   q2 = minA.z, minB.z, maxA.z, maxB.z   q3 = entryA, entryB, 0, 0
+// (x and y of a box together, z of both boxes together: the box test then runs on register pairs, rt_kernels.hip)
 //
 // Stack entry (one dword):
 //   bit31 = 1            leaf, components [start, start+count): count = bits 26..30, start = bits 0..25
@@ -113,6 +114,7 @@ struct KParams {
     int32_t row0, row1;
     const uint32_t* blockMap;  // launch block index -> (by << 16 | bx) of the 16x16-pixel block it renders, ~0u = none
     uint32_t* blockCost;       // InitialTrace only, may be null: hit pixels per wave, [(by * blocksX + bx) * 4 + wave]
+    uint32_t* blockSteps;      // TraceRays only, may be null: steps each wave needed for its rays, same indexing
     int blocksX;               // blocks per image row of this launch's grid
     unsigned long long* stats;  // sharded counters (rt_dispatch_stats order) or null
     int32_t statsLevel;         // 1: rays only, 2: everything

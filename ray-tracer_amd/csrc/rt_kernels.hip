@@ -47,7 +47,20 @@ DEV float dot(v3 a, v3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
 DEV v3 cross(v3 a, v3 b) { return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; }
 DEV float length(v3 a) { return __builtin_sqrtf(dot(a, a)); }
 DEV v3 normalize(v3 a) { float inv = 1.0f / __builtin_sqrtf(dot(a, a)); return a * inv; }
-DEV v3 rcp3(v3 a) { return {1.0f / a.x, 1.0f / a.y, 1.0f / a.z}; }
+// 1.0f / x, correctly rounded, in 3 instructions where that is proven: for 2^-126 <= |x| < 2^126 (exponent field 1..252:
+// x and 1/x both normal) v_rcp_f32 followed by one Newton step in fused multiply-adds equals the IEEE quotient for every
+// one of those 4.2e9 inputs on gfx950 (tools/micro/rcp_exhaustive.hip checks all 2^32 bit patterns).  Everything else
+// (zeros, denormals, huge values, infinities, NaNs) takes the compiler's full division sequence.
+DEV float rcpNormalRange(float x) {
+    const float r = __builtin_amdgcn_rcpf(x);
+    return __builtin_fmaf(__builtin_fmaf(-x, r, 1.0f), r, r);
+}
+DEV float rcpExact(float x) {
+    const uint32_t exponent = (__float_as_uint(x) >> 23) & 0xffu;
+    if (__builtin_expect(exponent - 1u > 251u, 0)) return 1.0f / x;
+    return rcpNormalRange(x);
+}
+DEV v3 rcp3(v3 a) { return {rcpExact(a.x), rcpExact(a.y), rcpExact(a.z)}; }
 // v_min_f32 / v_max_f32 return the non-NaN operand, which is the D3D min/max rule the kernels rely on.
 DEV float fminf_(float a, float b) { return __builtin_fminf(a, b); }
 DEV float fmaxf_(float a, float b) { return __builtin_fmaxf(a, b); }
@@ -220,15 +233,29 @@ DEV void writeTileCost(const KParams& P, bool hit) {
         P.blockCost[((size_t)(m >> 16) * P.blocksX + (m & 0xffffu)) * 4 + (threadIdx.x >> 6)] = (uint32_t)__builtin_popcountll(hitMask);
 }
 
+// Measured cost of this wave's tile: the steps the wave needed for its secondary rays (0 in lanes that cast none).  The
+// regions of the image are ranked by it for the launches of the following frames (k_order_blocks).
+DEV void writeTileSteps(const KParams& P, uint32_t steps) {
+    if (!P.blockSteps) return;
+    for (int off = 32; off > 0; off >>= 1) { const uint32_t o = __shfl_xor(steps, off, 64); steps = o > steps ? o : steps; }
+    const uint32_t m = P.blockMap[blockIdx.x];
+    if ((threadIdx.x & 63) == 0 && m != 0xffffffffu)
+        P.blockSteps[((size_t)(m >> 16) * P.blocksX + (m & 0xffffu)) * 4 + (threadIdx.x >> 6)] = steps;
+}
+
 // ---------------- BVH traversal ----------------
 struct Trav {
     float dst;        // closest hit distance along the world ray, INF on a miss
     float u, v;       // barycentrics of the closest hit
     int tri, obj;     // closest-hit triangle and scene object, -1 on a miss
+    uint32_t steps;     // steps the WAVE made while this lane's ray was traced (internal-node steps + trips); a cost measure
     int triChecks, bvChecks;  // debugData of RS:184,202,265,267
     // instrumentation (INSTR only)
     uint32_t hash;
     uint32_t pops, objVisits, triIters, iters;
+    // wave-level diagnostics (INSTR only; the same value in every lane): internal-node steps and leaf steps the wave
+    // executed, the lanes active in them, and the service steps
+    uint32_t wInt, wIntLanes, wLeaf, wLeafLanes, wSvc;
 };
 
 DEV float RayBVIntersect(v3 pos, v3 inv, v3 bmin, v3 bmax) {  // RS:148-161
@@ -240,6 +267,29 @@ DEV float RayBVIntersect(v3 pos, v3 inv, v3 bmin, v3 bmax) {  // RS:148-161
     float tFar = fminf_(fminf_(t2.x, t2.y), t2.z);
     bool didHit = tFar >= tNear && tFar > 0;
     return didHit ? (tNear > 0 ? tNear : 0.0f) : INF();
+}
+
+// Both child boxes of a wide record at once, on register pairs.  The record keeps the x and y bounds of a box together
+// and the z bounds of the two boxes together (rt_device.h), so with the ray's (x, y) as one register pair the twelve
+// subtractions and twelve multiplications of two RayBVIntersect calls are six v_pk_add_f32 and six v_pk_mul_f32 (the z
+// component is broadcast to both halves by the instruction's operand select).  Each component is the same IEEE subtract
+// and multiply as in RayBVIntersect (no contraction), so the distances are bit-identical.
+typedef float f2v __attribute__((ext_vector_type(2)));
+DEV float boxEntry(float tMinX, float tMinY, float tMinZ, float tMaxX, float tMaxY, float tMaxZ) {
+    float t1x = fminf_(tMinX, tMaxX), t1y = fminf_(tMinY, tMaxY), t1z = fminf_(tMinZ, tMaxZ);
+    float t2x = fmaxf_(tMinX, tMaxX), t2y = fmaxf_(tMinY, tMaxY), t2z = fmaxf_(tMinZ, tMaxZ);
+    float tNear = fmaxf_(fmaxf_(t1x, t1y), t1z);
+    float tFar = fminf_(fminf_(t2x, t2y), t2z);
+    bool didHit = tFar >= tNear && tFar > 0;
+    return didHit ? (tNear > 0 ? tNear : 0.0f) : INF();
+}
+DEV void RayBVIntersectPair(v3 pos, v3 inv, float4 q0, float4 q1, float4 q2, float& dstA, float& dstB) {
+    const f2v pxy = {pos.x, pos.y}, pzz = {pos.z, pos.z}, ixy = {inv.x, inv.y}, izz = {inv.z, inv.z};
+    const f2v aMin = ((f2v){q0.x, q0.y} - pxy) * ixy, aMax = ((f2v){q0.z, q0.w} - pxy) * ixy;
+    const f2v bMin = ((f2v){q1.x, q1.y} - pxy) * ixy, bMax = ((f2v){q1.z, q1.w} - pxy) * ixy;
+    const f2v zMin = ((f2v){q2.x, q2.y} - pzz) * izz, zMax = ((f2v){q2.z, q2.w} - pzz) * izz;  // (box A, box B)
+    dstA = boxEntry(aMin.x, aMin.y, zMin.x, aMax.x, aMax.y, zMax.x);
+    dstB = boxEntry(bMin.x, bMin.y, zMin.y, bMax.x, bMax.y, zMax.y);
 }
 
 // The RIS project's variant (BVH_RIS_DL .../RIS_BVH_RayTracer.compute:111-124) divides by the direction instead of
@@ -292,9 +342,11 @@ DEV void travBegin(const KParams& P, TravState& s, Trav& t, v3 wpos, v3 wdir, v3
     s.sp = 0; s.objBase = -1; s.objCur = 0; s.objEnd = 0; s.curObj = -1; s.localTri = -1;
     s.localU = 0; s.localV = 0;
     s.e = P.sceneRootEntry;
-    t.tri = -1; t.obj = -1; t.u = 0; t.v = 0; t.triChecks = 0; t.bvChecks = 0;
+    t.tri = -1; t.obj = -1; t.steps = 0; t.u = 0; t.v = 0; t.triChecks = 0; t.bvChecks = 0;
     if (INSTR) { t.hash = 2166136261u; t.pops = 1; t.objVisits = 0; t.triIters = 0; t.iters = 0; }
 }
+template <bool INSTR>
+DEV void travResetWaveCounts(Trav& t) { if (INSTR) t.wInt = t.wIntLanes = t.wLeaf = t.wLeafLanes = t.wSvc = 0; }
 // Next entry of the level being traversed, or ENTRY_NONE when that level's part of the stack is used up.
 template <bool INSTR>
 DEV void travPop(const KParams& P, TravState& s, Trav& t, const uint32_t* stk) {
@@ -342,11 +394,15 @@ DEV void travInternal(const KParams& P, TravState& s, Trav& t, uint32_t* stk) {
     const uint32_t e = s.e;
     if (INSTR) { t.iters++; t.hash = (t.hash ^ (0x80000000u | e)) * 16777619u; }
     const float4* rec = P.wide + (int64_t)e * 4;
-    const float4 q0 = rec[0], q1 = rec[1], q2 = rec[2], q3 = rec[3];
-    const float dstA = RIS ? RayBVIntersectDiv(s.rpos, s.rdir, V3(q0.x, q0.y, q0.z), V3(q0.w, q1.x, q1.y))
-                           : RayBVIntersect(s.rpos, s.rinv, V3(q0.x, q0.y, q0.z), V3(q0.w, q1.x, q1.y));
-    const float dstB = RIS ? RayBVIntersectDiv(s.rpos, s.rdir, V3(q1.z, q1.w, q2.x), V3(q2.y, q2.z, q2.w))
-                           : RayBVIntersect(s.rpos, s.rinv, V3(q1.z, q1.w, q2.x), V3(q2.y, q2.z, q2.w));
+    const float4 q0 = rec[0], q1 = rec[1], q2 = rec[2];
+    const float2 q3 = *(const float2*)(rec + 3);  // the two child entries
+    float dstA, dstB;
+    if (RIS) {
+        dstA = RayBVIntersectDiv(s.rpos, s.rdir, V3(q0.x, q0.y, q2.x), V3(q0.z, q0.w, q2.z));
+        dstB = RayBVIntersectDiv(s.rpos, s.rdir, V3(q1.x, q1.y, q2.y), V3(q1.z, q1.w, q2.w));
+    } else {
+        RayBVIntersectPair(s.rpos, s.rinv, q0, q1, q2, dstA, dstB);
+    }
     t.bvChecks += 2;
     const uint32_t eA = __float_as_uint(q3.x), eB = __float_as_uint(q3.y);
     const bool aFirst = dstA < dstB;  // the nearer child is visited first
@@ -398,7 +454,8 @@ DEV void travLeaf(const KParams& P, TravState& s, Trav& t, const uint32_t* stk) 
             v3 ao = s.rpos - V3(q0.x, q0.y, q0.z);
             v3 dao = cross(ao, s.rdir);
             float determinant = -dot(s.rdir, normalVector);
-            float invDet = 1 / determinant;
+            // the quotient only matters when determinant >= 1E-8 (didHit below); below 2^126 that is rcpNormalRange's domain
+            float invDet = determinant < 0x1p126f ? rcpNormalRange(determinant) : 1 / determinant;
             float dst = dot(ao, normalVector) * invDet;
             float u = dot(edgeAC, dao) * invDet;
             float v = -dot(edgeAB, dao) * invDet;
@@ -414,17 +471,25 @@ DEV void travLeaf(const KParams& P, TravState& s, Trav& t, const uint32_t* stk) 
 // t.dst) for lanes whose ray ends.
 template <bool INSTR, bool RIS>
 DEV void travTrip(const KParams& P, TravState& s, Trav& t, uint32_t* stk, bool& alive) {
+    if (INSTR && __builtin_amdgcn_ballot_w64(alive && s.e == ENTRY_NONE) != 0) t.wSvc++;
     if (alive && s.e == ENTRY_NONE) alive = travService<INSTR, RIS>(P, s, t, stk);
     // The phase is left once at least RT_LEAF_NUM / RT_LEAF_DEN of the lanes still at work wait for a leaf or for
     // service, i.e. once the lanes holding an internal entry are few enough (the live lanes do not change in it).
     const int nAlive = __builtin_popcountll(__builtin_amdgcn_ballot_w64(alive));
     bool isInt = alive && s.e != ENTRY_NONE && (s.e & LEAF_BITS) == 0;
     int nInt = __builtin_popcountll(__builtin_amdgcn_ballot_w64(isInt));
+    t.steps++;
     while (nInt != 0) {
+        t.steps++;
+        if (INSTR) { t.wInt++; t.wIntLanes += (uint32_t)nInt; }
         if (isInt) travInternal<INSTR, RIS>(P, s, t, stk);
         isInt = alive && s.e != ENTRY_NONE && (s.e & LEAF_BITS) == 0;
         nInt = __builtin_popcountll(__builtin_amdgcn_ballot_w64(isInt));
         if (RT_LEAF_DEN * (nAlive - nInt) >= RT_LEAF_NUM * nAlive) break;
+    }
+    if (INSTR) {
+        const int nLeaf = __builtin_popcountll(__builtin_amdgcn_ballot_w64(alive && s.e != ENTRY_NONE && (s.e & LEAF_BITS) != 0));
+        if (nLeaf) { t.wLeaf++; t.wLeafLanes += (uint32_t)nLeaf; }
     }
     if (alive && s.e != ENTRY_NONE && (s.e & LEAF_BITS) != 0) travLeaf<INSTR, RIS>(P, s, t, stk);
 }
@@ -486,12 +551,20 @@ DEV void waveAdd(unsigned long long* dst, uint32_t v) {
     if ((threadIdx.x & 63) == 0) atomicAdd(dst + (blockIdx.x % STAT_SHARDS) * 8, (unsigned long long)v);
 }
 // Diagnostics (instrumented variants only): lifetime and loop-trip counts of each wave of a launch.
-DEV void writeWaveProfile(const KParams& P, unsigned long long tStart, uint32_t iters) {
+DEV void writeWaveProfile(const KParams& P, unsigned long long tStart, uint32_t iters, const Trav& t) {
     uint32_t mx = iters, sm = iters;
     for (int off = 32; off > 0; off >>= 1) { uint32_t o = __shfl_xor(mx, off, 64); mx = o > mx ? o : mx; sm += __shfl_xor(sm, off, 64); }
+    // the wave-level counts are only defined in lanes that traversed; take the largest
+    uint32_t wv[5] = {t.wInt, t.wIntLanes, t.wLeaf, t.wLeafLanes, t.wSvc};
+    for (int k = 0; k < 5; k++) {
+        uint32_t v = iters ? wv[k] : 0;
+        for (int off = 32; off > 0; off >>= 1) { uint32_t o = __shfl_xor(v, off, 64); v = o > v ? o : v; }
+        wv[k] = v;
+    }
     if ((threadIdx.x & 63) == 0) {
-        unsigned long long* w = P.waveProfile + ((size_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 4;
+        unsigned long long* w = P.waveProfile + ((size_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * 8;
         w[0] = tStart; w[1] = wall_clock64(); w[2] = mx; w[3] = sm;
+        w[4] = wv[0]; w[5] = wv[1]; w[6] = wv[2]; w[7] = (unsigned long long)wv[3] | ((unsigned long long)wv[4] << 32);
     }
 }
 enum { ST_RAYS = 0, ST_POPS, ST_BVCHECKS, ST_OBJVISITS, ST_TRIITERS, ST_TRICHECKS, ST_NEIGHBOURS, ST_ACTIVE };
@@ -626,14 +699,18 @@ DEV v2 GetLastUV(const KParams& P, v3 worldFocalPos) {  // RS:451-461
 // =====================================================================================================
 // InitialTrace, first half (RS:463-491,496-509): camera ray, closest hit, G-buffer outputs.
 // =====================================================================================================
+#ifndef RT_PRIMARY_WAVES
+#define RT_PRIMARY_WAVES 5
+#endif
 template <bool INSTR>
-__global__ __launch_bounds__(256, RT_MIN_WAVES) void k_primary(const KParams P) {
+__global__ __launch_bounds__(256, RT_PRIMARY_WAVES) void k_primary(const KParams P) {
     extern __shared__ uint32_t lds[];
     const Pixel px = pixelOfThread(P);
     uint32_t rays = 0;
     Trav t;
     t.dst = INF();
     if (INSTR) { t.pops = t.objVisits = t.triIters = t.iters = 0; t.triChecks = t.bvChecks = 0; }
+    travResetWaveCounts<INSTR>(t);
     unsigned long long tStart = 0;
     if (INSTR && P.waveProfile) tStart = wall_clock64();
     if (px.active) {
@@ -673,7 +750,7 @@ __global__ __launch_bounds__(256, RT_MIN_WAVES) void k_primary(const KParams P) 
         }
     }
     writeTileCost(P, px.active && t.dst != INF());
-    if (INSTR && P.waveProfile && P.waveProfileKernel == 0) writeWaveProfile(P, tStart, px.active ? t.iters : 0);
+    if (INSTR && P.waveProfile && P.waveProfileKernel == 0) writeWaveProfile(P, tStart, px.active ? t.iters : 0, t);
     if (P.stats) {
         waveAdd(P.stats + ST_RAYS, rays);
         if (INSTR) {
@@ -735,6 +812,7 @@ __global__ __launch_bounds__(256, RT_MIN_WAVES) void k_candidates(const KParams 
     uint32_t rays = 0;
     Trav t;
     if (INSTR) { t.pops = t.objVisits = t.triIters = t.iters = 0; t.triChecks = t.bvChecks = 0; }
+    travResetWaveCounts<INSTR>(t);
     unsigned long long tStart = 0;
     if (INSTR && P.waveProfile) tStart = wall_clock64();
     if (px.active) {
@@ -793,7 +871,7 @@ __global__ __launch_bounds__(256, RT_MIN_WAVES) void k_candidates(const KParams 
             if ((int64_t)pixelIndex < P.cand.count) storeReservoir(P.cand, pixelIndex, res);
         }
     }
-    if (INSTR && P.waveProfile && P.waveProfileKernel == 1) writeWaveProfile(P, tStart, rays ? t.iters : 0);
+    if (INSTR && P.waveProfile && P.waveProfileKernel == 1) writeWaveProfile(P, tStart, rays ? t.iters : 0, t);
     if (P.stats) {
         waveAdd(P.stats + ST_RAYS, rays);
         if (INSTR) {
@@ -940,6 +1018,7 @@ __global__ __launch_bounds__(256) void k_transfer(const KParams P) {
     if (P.stats && P.statsLevel >= 2) waveAdd(P.stats + ST_ACTIVE, active ? 1u : 0u);
 }
 
+
 // =====================================================================================================
 // TraceRays (RS:645-815)
 // =====================================================================================================
@@ -956,7 +1035,9 @@ template <bool INSTR>
 __global__ __launch_bounds__(256, 5) void k_trace_rays(const KParams P) {
     extern __shared__ uint32_t lds[];
     const Pixel px = pixelOfThread(P);
-    uint32_t rays = 0, pops = 0, bvc = 0, objv = 0, trii = 0, tric = 0, iters = 0;
+    uint32_t rays = 0, pops = 0, bvc = 0, objv = 0, trii = 0, tric = 0, iters = 0, steps = 0;
+    Trav acc;
+    if (INSTR) acc.wInt = acc.wIntLanes = acc.wLeaf = acc.wLeafLanes = acc.wSvc = 0;
     unsigned long long tStart = 0;
     if (INSTR && P.waveProfile) tStart = wall_clock64();
     // every lane's colour is stored once, after the wave has reconverged: lanes that take the short branches would
@@ -1021,10 +1102,13 @@ __global__ __launch_bounds__(256, 5) void k_trace_rays(const KParams P) {
                 else indirectLight = indirectLight + emittedLight * rayColor;
                 if (bounceCount != P.MaxBounceCount) {
                     Trav t;
+                    travResetWaveCounts<INSTR>(t);
                     TRAVERSE<INSTR>(P, rpos, rdir, rinv, laneStack(lds, P.stackDepth), t);
                     rays++;
+                    steps += t.steps;
                     if (INSTR) {
                         iters += t.iters;
+                        acc.wInt += t.wInt; acc.wIntLanes += t.wIntLanes; acc.wLeaf += t.wLeaf; acc.wLeafLanes += t.wLeafLanes; acc.wSvc += t.wSvc;
                         pops += t.pops; bvc += (uint32_t)t.bvChecks; objv += t.objVisits; trii += t.triIters;
                         tric += (uint32_t)t.triChecks;
                         // chain the per-ray hashes the way one running hash over all rays would evolve
@@ -1042,7 +1126,8 @@ __global__ __launch_bounds__(256, 5) void k_trace_rays(const KParams P) {
         }
     }
     if (px.active) storeRT(P.result, (int64_t)px.y * P.ResX + px.x, colour);
-    if (INSTR && P.waveProfile && P.waveProfileKernel == 2) writeWaveProfile(P, tStart, iters);
+    writeTileSteps(P, steps);
+    if (INSTR && P.waveProfile && P.waveProfileKernel == 2) writeWaveProfile(P, tStart, iters, acc);
     if (P.stats) {
         waveAdd(P.stats + ST_RAYS, rays);
         if (INSTR) {
@@ -1102,9 +1187,9 @@ __global__ void k_build_wide(const rt_bv* BVs, int64_t nBVs, float4* wide) {
         B = A;
         if (cA < nBVs) A = BVs[cA];
         if (cB < nBVs) B = BVs[cB];
-        q0 = make_float4(A.min.x, A.min.y, A.min.z, A.max.x);
-        q1 = make_float4(A.max.y, A.max.z, B.min.x, B.min.y);
-        q2 = make_float4(B.min.z, B.max.x, B.max.y, B.max.z);
+        q0 = make_float4(A.min.x, A.min.y, A.max.x, A.max.y);
+        q1 = make_float4(B.min.x, B.min.y, B.max.x, B.max.y);
+        q2 = make_float4(A.min.z, B.min.z, A.max.z, B.max.z);
         q3 = make_float4(__uint_as_float(entryOf(BVs, nBVs, cA)), __uint_as_float(entryOf(BVs, nBVs, cB)), 0, 0);
     }
     wide[n * 4 + 0] = q0; wide[n * 4 + 1] = q1; wide[n * 4 + 2] = q2; wide[n * 4 + 3] = q3;
@@ -1197,7 +1282,10 @@ __global__ void k_recs_to_aos(Recs rc, float* aos, int64_t first, int64_t n) {
 #define RT_REGION 4   // blocks per side of a region
 #endif
 constexpr int ORDER_MAX_REGIONS = 4096;
-__global__ __launch_bounds__(1024) void k_order_blocks(const uint32_t* costW, int BX, int BY, uint32_t* dyn, unsigned nDyn) {
+// byMax = 0: costW holds hit pixels per wave, a region's rank is their sum in steps of 64; byMax = 1: costW holds the
+// steps each wave needed for its secondary rays, a region's rank is its longest wave in steps of 8 (the waves with the
+// longest rays must start first: a wave cannot end before its longest ray does).
+__global__ __launch_bounds__(1024) void k_order_blocks(const uint32_t* costW, int BX, int BY, uint32_t* dyn, unsigned nDyn, int byMax) {
     __shared__ uint32_t hist[66], order[ORDER_MAX_REGIONS], regionCost[ORDER_MAX_REGIONS];
     __shared__ uint8_t bucketOf[ORDER_MAX_REGIONS];
     constexpr int RS = RT_REGION;
@@ -1208,11 +1296,13 @@ __global__ __launch_bounds__(1024) void k_order_blocks(const uint32_t* costW, in
     __syncthreads();
     for (int b = t; b < BX * BY; b += 1024) {  // one 16-byte load per block: its four waves' hit counts
         const uint4 w = ((const uint4*)costW)[b];
-        atomicAdd(&regionCost[(b / BX / RS) * RX + (b % BX) / RS], w.x + w.y + w.z + w.w);
+        uint32_t* rc = &regionCost[(b / BX / RS) * RX + (b % BX) / RS];
+        if (byMax) atomicMax(rc, max(max(w.x, w.y), max(w.z, w.w)));
+        else atomicAdd(rc, w.x + w.y + w.z + w.w);
     }
     __syncthreads();
     for (int r = t; r < R; r += 1024) {
-        const uint32_t c = regionCost[r] * 16 / (RS * RS);  // as if the region had 16 blocks
+        const uint32_t c = byMax ? regionCost[r] * 8 : regionCost[r] * 16 / (RS * RS);  // hit counts: as if the region had 16 blocks
         const uint32_t step = c / 64 > 64 ? 64 : c / 64;
         bucketOf[r] = (uint8_t)(64 - step);  // bucket 0 = heaviest
         atomicAdd(&hist[64 - step], 1u);

@@ -83,6 +83,7 @@ __global__ __launch_bounds__(256, RT_MIN_WAVES) void k_ris_primary(const KParams
     Trav t;
     t.dst = INF();
     if (INSTR) { t.pops = t.objVisits = t.triIters = t.iters = 0; t.triChecks = t.bvChecks = 0; }
+    travResetWaveCounts<INSTR>(t);
     if (px.active) {
         const uint32_t idx = (uint32_t)px.x, idy = (uint32_t)px.y;
         float focalPosX = ((float)idx / (float)P.ResX - 0.5f) * 2.0f * P.ViewSpaceDimsX;
@@ -306,6 +307,7 @@ __global__ __launch_bounds__(256, RT_MIN_WAVES) void k_ris_trace_rays(const KPar
                     rayColor = rayColor * lerp3(V3(material.color), V3(material.specularColor), isSpecularBounce ? 1.0f : 0.0f);
                     if (bounceCount != P.risMaxBounceCount) {
                         Trav t;
+                        travResetWaveCounts<INSTR>(t);
                         TRAVERSE<INSTR, true>(P, rpos, rdir, rdir, laneStack(lds, P.stackDepth), t);
                         rays++;
                         if (INSTR) {

@@ -49,9 +49,10 @@ struct rt_ctx_s {
     int statsLevel = 0;  // 0 off, 1 rays + active pixels, 2 all counters (instrumented kernel variants)
     unsigned long long* statsDev = nullptr;  // IK_COUNT x STAT_SHARDS x 8 counters, accumulated until read
     // workgroup -> image block table of the per-pixel kernels (see buildBlockMap)
-    // dev: the static order; dyn: the heaviest-first order k_order_blocks rebuilds after every InitialTrace from the
-    // per-wave hit counts in cost (null when the grid has more regions than that kernel sorts)
-    struct BlockMap { int bx, by; uint32_t* dev; unsigned n; uint32_t* dyn; uint32_t* cost; unsigned nDyn; bool dynValid; unsigned age; };
+    // dev: the static order; dyn: the heaviest-first order k_order_blocks rebuilds after InitialTrace's primary rays, from the
+    // per-wave hit counts in cost until a TraceRays has run on this grid, then from the steps its waves needed (steps);
+    // null when the grid has more regions than that kernel sorts
+    struct BlockMap { int bx, by; uint32_t* dev; unsigned n; uint32_t* dyn; uint32_t* cost; unsigned nDyn; bool dynValid; unsigned age; uint32_t* steps; bool stepsValid; bool rankedBySteps; uint32_t* dynHits; };
     std::vector<BlockMap> blockMaps;  // one per band height in use (a multi-GPU host alternates between a few)
     uint32_t* scratch = nullptr;  // this device's address of the file-scope `scratch` array
     bool noAlloc = false;         // set for the duration of rt_dispatch_no_alloc
@@ -519,7 +520,8 @@ int pixelGrid(rt_ctx ctx, KParams& P, int gx, int gy, unsigned* blocks, rt_ctx_s
         m.n = m.nDyn = (regions + 7) / 8 * (8 * RT_REGION * RT_REGION);
         m.dynValid = false; m.age = 0;
         HIP_TRY(ctx, hipMemsetAsync(m.cost, 0, (size_t)bx * by * 4 * sizeof(uint32_t), ctx->stream));
-        hipLaunchKernelGGL(k_order_blocks, dim3(1), dim3(1024), 0, ctx->stream, m.cost, m.bx, m.by, m.dyn, m.nDyn);
+        m.steps = nullptr; m.stepsValid = false; m.rankedBySteps = false; m.dynHits = nullptr;
+        hipLaunchKernelGGL(k_order_blocks, dim3(1), dim3(1024), 0, ctx->stream, m.cost, m.bx, m.by, m.dyn, m.nDyn, 0);
         HIP_TRY(ctx, hipGetLastError());
         P.blockMap = m.dev;
         *blocks = m.n;
@@ -540,11 +542,13 @@ int pixelGrid(rt_ctx ctx, KParams& P, int gx, int gy, unsigned* blocks, rt_ctx_s
         hipError_t e = hipFree(old.dev);
         if (old.dyn) e = hipFree(old.dyn);
         if (old.cost) e = hipFree(old.cost);
+        if (old.steps) e = hipFree(old.steps);
+        if (old.dynHits) e = hipFree(old.dynHits);
         (void)e;
         ctx->blockMaps.erase(ctx->blockMaps.begin());
     }
     std::vector<uint32_t> map = buildBlockMap(bx, by, mode);
-    rt_ctx_s::BlockMap m = {(int)bx, (int)by, nullptr, (unsigned)map.size(), nullptr, nullptr, 0, false, 0};
+    rt_ctx_s::BlockMap m = {(int)bx, (int)by, nullptr, (unsigned)map.size(), nullptr, nullptr, 0, false, 0, nullptr, false, false, nullptr};
     HIP_TRY(ctx, hipMalloc((void**)&m.dev, map.size() * 4));
     HIP_TRY(ctx, hipMemcpy(m.dev, map.data(), map.size() * 4, hipMemcpyHostToDevice));
     const unsigned regions = ((bx + RT_REGION - 1) / RT_REGION) * ((by + RT_REGION - 1) / RT_REGION);
@@ -553,6 +557,9 @@ int pixelGrid(rt_ctx ctx, KParams& P, int gx, int gy, unsigned* blocks, rt_ctx_s
         HIP_TRY(ctx, hipMalloc((void**)&m.dyn, (size_t)m.nDyn * 4));
         HIP_TRY(ctx, hipMalloc((void**)&m.cost, (size_t)bx * by * 4 * 4));
         HIP_TRY(ctx, hipMemset(m.cost, 0, (size_t)bx * by * 4 * 4));
+        HIP_TRY(ctx, hipMalloc((void**)&m.dynHits, (size_t)m.nDyn * 4));
+        HIP_TRY(ctx, hipMalloc((void**)&m.steps, (size_t)bx * by * 4 * 4));
+        HIP_TRY(ctx, hipMemset(m.steps, 0, (size_t)bx * by * 4 * 4));
     }
     ctx->blockMaps.push_back(m);
     return use(ctx->blockMaps.back());
@@ -563,8 +570,13 @@ void reorderBlocks(rt_ctx ctx, rt_ctx_s::BlockMap* m) {
     if (!m || !m->dyn) return;
     // the ranking moves slowly from frame to frame: refresh it on the first frame and then every eighth (a stale
     // order is still a complete one; it only costs a little balance after a camera cut)
-    if (m->dynValid && (++m->age % 8) != 0) return;
-    hipLaunchKernelGGL(k_order_blocks, dim3(1), dim3(1024), 0, ctx->stream, m->cost, m->bx, m->by, m->dyn, m->nDyn);
+    const bool measured = m->steps && m->stepsValid;
+    const bool firstMeasured = measured && !m->rankedBySteps;   // the first frame after measurements exist re-ranks at once
+    if (m->dynValid && !firstMeasured && (++m->age % 8) != 0) return;
+    m->rankedBySteps = measured;
+    hipLaunchKernelGGL(k_order_blocks, dim3(1), dim3(1024), 0, ctx->stream, measured ? m->steps : m->cost, m->bx, m->by, m->dyn, m->nDyn, measured ? 1 : 0);
+    // the primary rays' cost follows the hit count, not the secondary rays' steps: their launch gets a ranking of its own
+    if (m->dynHits) hipLaunchKernelGGL(k_order_blocks, dim3(1), dim3(1024), 0, ctx->stream, m->cost, m->bx, m->by, m->dynHits, m->nDyn, 0);
     m->dynValid = true;
 }
 
@@ -630,7 +642,7 @@ int dispatchReSTIR(rt_shader sh, int kernel, int gx, int gy) {
         instr = true;
     }
     if (rt_buffer wp = boundBuffer(sh, kernel, "WaveProfile")) {  // diagnostics
-        if (wp->stride != 32 || wp->count < (int64_t)blocks * 8 + 64) return fail(ctx, RT_ERR_INVALID_ARG, "WaveProfile needs stride 32 and %u records", blocks * 8 + 64);
+        if (wp->stride != 64 || wp->count < (int64_t)blocks * 4 + 64) return fail(ctx, RT_ERR_INVALID_ARG, "WaveProfile needs stride 64 and %u records", blocks * 4 + 64);
         P.waveProfile = (unsigned long long*)wp->dev;
         static const int which = [] { const char* e = getenv("RT_WAVE_PROFILE_KERNEL"); return e ? atoi(e) : 0; }();
         P.waveProfileKernel = which;
@@ -657,6 +669,7 @@ int dispatchReSTIR(rt_shader sh, int kernel, int gx, int gy) {
             size_t ldsBytes = (size_t)WAVES_PER_BLOCK * P.stackDepth * 64 * 4;
             {
                 if (grid) P.blockCost = grid->cost;
+                if (grid && grid->dynValid && grid->dynHits) { P.blockMap = grid->dynHits; blocks = grid->nDyn; }
                 LaunchScope ls(ctx, IK_PRIMARY, &P);
                 if (instr) hipLaunchKernelGGL(k_primary<true>, dim3(blocks), dim3(256), ldsBytes, ctx->stream, P);
                 else hipLaunchKernelGGL(k_primary<false>, dim3(blocks), dim3(256), ldsBytes, ctx->stream, P);
@@ -710,6 +723,7 @@ int dispatchReSTIR(rt_shader sh, int kernel, int gx, int gy) {
             optionalTex(sh, kernel, "EnvironmentMap", P.env);
             if (!blocks) break;
             size_t ldsBytes = (size_t)WAVES_PER_BLOCK * P.stackDepth * 64 * 4;
+            if (grid && grid->steps) { P.blockSteps = grid->steps; grid->stepsValid = true; }
             {
                 LaunchScope ls(ctx, IK_TRACE_RAYS, &P);
                 if (instr) hipLaunchKernelGGL(k_trace_rays<true>, dim3(blocks), dim3(256), ldsBytes, ctx->stream, P);
@@ -909,7 +923,7 @@ void rt_destroy(rt_ctx ctx) {
         if (pr.objRoot) e = hipFree(pr.objRoot);
     }
     if (ctx->statsDev) e = hipFree(ctx->statsDev);
-    for (auto& m : ctx->blockMaps) { e = hipFree(m.dev); if (m.dyn) e = hipFree(m.dyn); if (m.cost) e = hipFree(m.cost); }
+    for (auto& m : ctx->blockMaps) { e = hipFree(m.dev); if (m.dyn) e = hipFree(m.dyn); if (m.cost) e = hipFree(m.cost); if (m.steps) e = hipFree(m.steps); if (m.dynHits) e = hipFree(m.dynHits); }
     for (auto& t : ctx->pending) { e = hipEventDestroy(t.start); e = hipEventDestroy(t.stop); }
     for (auto ev : ctx->freeEvents) e = hipEventDestroy(ev);
     e = hipStreamDestroy(ctx->stream);

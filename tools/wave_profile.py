@@ -11,13 +11,13 @@ for _ in range(3):
     drv.render_frame()
 nb = 8192 * 2
 which = int(os.environ.get("RT_WAVE_PROFILE_KERNEL", "0"))
-wp = ctx.create_buffer(nb * 8 + 64, 32)
+wp = ctx.create_buffer(nb * 4 + 64, 64)
 ctx.check(ctx.lib.rt_set_buffer(drv.shader("rt"), 4 if which == 2 else 0, b"WaveProfile", wp), "bind")
 drv.update_per_frame()
 for st in range(4):
     drv.run_stage(st)
 ctx.sync()
-a = ctx.get_buffer(wp, np.dtype([("t0", "<u8"), ("t1", "<u8"), ("mx", "<u8"), ("sm", "<u8")]))
+a = ctx.get_buffer(wp, np.dtype([("t0", "<u8"), ("t1", "<u8"), ("mx", "<u8"), ("sm", "<u8"), ("wInt", "<u8"), ("wIntLanes", "<u8"), ("wLeaf", "<u8"), ("wLeafSvc", "<u8")]))
 a = a[a["t1"] > 0]
 dur = (a["t1"] - a["t0"]).astype(np.float64) / 100.0  # wall_clock64 ticks at 100 MHz -> microseconds
 span = (a["t1"].max() - a["t0"].min()) / 100.0
@@ -34,3 +34,11 @@ t0 = (a["t0"] - a["t0"].min()) / 100.0
 for lo in range(0, int(span) + 1, max(1, int(span / 12))):
     sel = (t0 <= lo) & ((a["t1"] - a["t0"].min()) / 100.0 > lo)
     print(f"t={lo:5d} us resident waves {sel.sum():5d} heavy {(sel & heavy).sum():5d}")
+
+wInt, wIntL, wLeaf = a["wInt"].astype(np.float64), a["wIntLanes"].astype(np.float64), a["wLeaf"].astype(np.float64)
+wLeafL, wSvc = (a["wLeafSvc"] & 0xffffffff).astype(np.float64), (a["wLeafSvc"] >> 32).astype(np.float64)
+h = heavy
+print(f"wave-level steps in heavy waves: internal {wInt[h].sum():.0f} (active lanes/step {wIntL[h].sum() / wInt[h].sum():.1f}), "
+      f"leaf {wLeaf[h].sum():.0f} (active lanes/step {wLeafL[h].sum() / max(1, wLeaf[h].sum()):.1f}), service {wSvc[h].sum():.0f}")
+print(f"per heavy wave: internal steps {wInt[h].mean():.1f}, leaf steps {wLeaf[h].mean():.1f}, service {wSvc[h].mean():.1f}, max lane iters {mx[h].mean():.1f}")
+print(f"us per wave-level step (internal+leaf): {(dur[h].sum() / (wInt[h].sum() + wLeaf[h].sum())):.3f}")
