@@ -183,6 +183,20 @@ typedef struct {
 int rt_buffer_map_rows(rt_buffer buf, int width, int row0, int row1, rt_segment out[4], int* count);
 int rt_texture_map_rows(rt_texture tex, int row0, int row1, rt_segment* out);
 
+/* ---- second stream for transfers (no counterpart in the reference) ---------------------------------------- */
+
+/* A second HIP stream (hipStream_t) of the context, for transfers that should overlap the kernels: a multi-GPU host
+ * puts its halo exchanges and frame-buffer gathers on it.  Created at the first call; rt_sync waits for both streams. */
+void* rt_transfer_stream(rt_ctx ctx);
+/* Orders the two streams against each other: everything enqueued so far on stream `first` (0 = the dispatch stream,
+ * 1 = the transfer stream) completes before anything enqueued LATER on the other stream starts.  Nothing blocks on the
+ * host. */
+int rt_stream_order(rt_ctx ctx, int first);
+/* Time stamps for measuring that overlap: rt_mark records stamp `slot` (0..63) at the current end of a stream
+ * (0 or 1); rt_mark_elapsed waits for both stamps and returns the milliseconds from stamp a to stamp b. */
+int rt_mark(rt_ctx ctx, int stream, int slot);
+int rt_mark_elapsed(rt_ctx ctx, int slot_a, int slot_b, double* milliseconds);
+
 /* ---- measurement (no counterpart in the reference) -------------------------------------------------------- */
 
 /* Work counters of a (shader, kernel) pair, summed over every dispatch since they were last read.

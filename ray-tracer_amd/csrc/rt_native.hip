@@ -44,6 +44,9 @@ static __device__ __align__(256) uint32_t scratch[NOALLOC_TABLE_WORDS + NOALLOC_
 struct rt_ctx_s {
     int device = 0;
     hipStream_t stream = nullptr;
+    hipStream_t transferStream = nullptr;  // created by rt_transfer_stream
+    hipEvent_t orderEvent[2] = {nullptr, nullptr};
+    hipEvent_t marks[64] = {};
     std::string err;
     int row0 = 0, row1 = 0;
     int statsLevel = 0;  // 0 off, 1 rays + active pixels, 2 all counters (instrumented kernel variants)
@@ -926,6 +929,9 @@ void rt_destroy(rt_ctx ctx) {
     for (auto& m : ctx->blockMaps) { e = hipFree(m.dev); if (m.dyn) e = hipFree(m.dyn); if (m.cost) e = hipFree(m.cost); if (m.steps) e = hipFree(m.steps); if (m.dynHits) e = hipFree(m.dynHits); }
     for (auto& t : ctx->pending) { e = hipEventDestroy(t.start); e = hipEventDestroy(t.stop); }
     for (auto ev : ctx->freeEvents) e = hipEventDestroy(ev);
+    for (auto ev : ctx->orderEvent) if (ev) e = hipEventDestroy(ev);
+    for (auto ev : ctx->marks) if (ev) e = hipEventDestroy(ev);
+    if (ctx->transferStream) { e = hipStreamSynchronize(ctx->transferStream); e = hipStreamDestroy(ctx->transferStream); }
     e = hipStreamDestroy(ctx->stream);
     (void)e;
     delete ctx;
@@ -934,6 +940,51 @@ void rt_destroy(rt_ctx ctx) {
 int rt_sync(rt_ctx ctx) {
     if (!ctx) return RT_ERR_INVALID_ARG;
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->transferStream) HIP_TRY(ctx, hipStreamSynchronize(ctx->transferStream));
+    return RT_OK;
+}
+
+void* rt_transfer_stream(rt_ctx ctx) {
+    if (!ctx) return nullptr;
+    if (!ctx->transferStream) {
+        if (hipSetDevice(ctx->device) != hipSuccess || hipStreamCreateWithFlags(&ctx->transferStream, hipStreamNonBlocking) != hipSuccess) {
+            ctx->transferStream = nullptr;
+            fail(ctx, RT_ERR_NO_DEVICE, "the transfer stream could not be created");
+        }
+    }
+    return (void*)ctx->transferStream;
+}
+int rt_stream_order(rt_ctx ctx, int first) {
+    if (!ctx || first < 0 || first > 1) return RT_ERR_INVALID_ARG;
+    int rc = useDevice(ctx);
+    if (rc) return rc;
+    if (!rt_transfer_stream(ctx)) return RT_ERR_NO_DEVICE;
+    hipEvent_t& ev = ctx->orderEvent[first];
+    if (!ev) HIP_TRY(ctx, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    hipStream_t from = first == 0 ? ctx->stream : ctx->transferStream, to = first == 0 ? ctx->transferStream : ctx->stream;
+    HIP_TRY(ctx, hipEventRecord(ev, from));
+    HIP_TRY(ctx, hipStreamWaitEvent(to, ev, 0));
+    return RT_OK;
+}
+int rt_mark(rt_ctx ctx, int stream, int slot) {
+    if (!ctx || stream < 0 || stream > 1 || slot < 0 || slot >= 64) return RT_ERR_INVALID_ARG;
+    int rc = useDevice(ctx);
+    if (rc) return rc;
+    if (stream == 1 && !rt_transfer_stream(ctx)) return RT_ERR_NO_DEVICE;
+    if (!ctx->marks[slot]) HIP_TRY(ctx, hipEventCreate(&ctx->marks[slot]));
+    HIP_TRY(ctx, hipEventRecord(ctx->marks[slot], stream == 0 ? ctx->stream : ctx->transferStream));
+    return RT_OK;
+}
+int rt_mark_elapsed(rt_ctx ctx, int a, int b, double* ms) {
+    if (!ctx || !ms || a < 0 || a >= 64 || b < 0 || b >= 64) return RT_ERR_INVALID_ARG;
+    if (!ctx->marks[a] || !ctx->marks[b]) return fail(ctx, RT_ERR_INVALID_ARG, "stamp %d or %d was never recorded", a, b);
+    int rc = useDevice(ctx);
+    if (rc) return rc;
+    HIP_TRY(ctx, hipEventSynchronize(ctx->marks[a]));
+    HIP_TRY(ctx, hipEventSynchronize(ctx->marks[b]));
+    float f = 0;
+    HIP_TRY(ctx, hipEventElapsedTime(&f, ctx->marks[a], ctx->marks[b]));
+    *ms = f;
     return RT_OK;
 }
 const char* rt_last_error(rt_ctx ctx) { return ctx ? ctx->err.c_str() : "null context"; }

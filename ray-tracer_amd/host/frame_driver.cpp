@@ -398,12 +398,24 @@ rt_shader rth_main_shader(rth_main m, const char* name) {
 
 // ==================================================================================================================
 // Multi-GPU frame loop: one process per GPU, the image cut into row bands, halos and the displayed image moved with
-// RCCL point-to-point transfers on the context's own stream.  The reference is single-GPU; this is the sharding the
-// path admits (every kernel reads only its own pixel except SpatialReusePass, which reads reservoirs and depths up to
-// MaxOffset + 1 rows away).  The schedule below is the one ray-tracer_amd/multigpu.py runs over torch.distributed
-// (and that the CPU tests check against the single-process result); here no Python runs between frames.
+// RCCL point-to-point transfers.  The reference is single-GPU; this is the sharding the path admits (every kernel
+// reads only its own pixel except SpatialReusePass, which reads reservoirs and depths up to MaxOffset + 1 rows away).
+// The schedule is the one ray-tracer_amd/multigpu.py runs over torch.distributed (and that the CPU tests check
+// against the single-process result); here no Python runs between frames.
+//
+// Streams.  Kernels run on the context's dispatch stream, all transfers on its transfer stream (rt_transfer_stream),
+// with ONE communicator: every rank enqueues the same sequence of grouped send/recv calls on that one stream
+// (halo f, gather f, halo f+1, ...), which is the ordering RCCL asks for.  Per frame:
+//   dispatch stream : InitialTrace, TemporalReuse | pass 0 on the interior rows | pass 0 on the border rows, later
+//                     passes, TransferToOriginal | TraceRays, AccumulateFrames
+//   transfer stream :                             | halo exchange ............ |        | gather of Result (overlaps
+//                                                                                          the next frame's InitialTrace)
+// The interior rows of the first pass read nothing a neighbour owns, so they run while the halos travel; TraceRays
+// of frame f+1 is the first kernel that writes what gather f reads (this rank's band of Result) and waits for it.
 // ==================================================================================================================
 #include <dlfcn.h>
+
+#include <algorithm>
 
 namespace {
 
@@ -418,6 +430,7 @@ struct Rccl {
     int (*GroupEnd)() = nullptr;
     int (*Send)(const void*, size_t, int, int, comm_t, void*) = nullptr;
     int (*Recv)(void*, size_t, int, int, comm_t, void*) = nullptr;
+    int (*AllReduce)(const void*, void*, size_t, int, int, comm_t, void*) = nullptr;
     const char* (*GetErrorString)(int) = nullptr;
     bool ok = false;
     std::string why;
@@ -434,12 +447,18 @@ struct Rccl {
         GroupEnd = (decltype(GroupEnd))sym("ncclGroupEnd");
         Send = (decltype(Send))sym("ncclSend");
         Recv = (decltype(Recv))sym("ncclRecv");
+        AllReduce = (decltype(AllReduce))sym("ncclAllReduce");
         GetErrorString = (decltype(GetErrorString))sym("ncclGetErrorString");
         ok = why.empty();
     }
 };
 Rccl& rccl() { static Rccl r; return r; }
-const int NCCL_UINT8 = 1;  // ncclUint8 / ncclChar share the value 1 and 0; bytes are bytes either way
+const int NCCL_UINT8 = 1;   // ncclUint8
+const int NCCL_DOUBLE = 8;  // ncclFloat64
+const int NCCL_SUM = 0;
+
+// stamps (rt_mark slots) of one frame, for the per-rank breakdown
+enum { MK_FRAME = 0, MK_PRE, MK_INTERIOR, MK_HALO0, MK_HALO1, MK_POST0, MK_END, MK_GATHER0, MK_GATHER1 };
 
 }  // namespace
 
@@ -451,6 +470,10 @@ struct rth_mg_s {
     int rank = 0, world = 1;
     std::vector<int> bounds;
     Rccl::comm_t comm = nullptr;
+    bool timing = false;
+    bool gatherPending = false;  // a gather is in flight on the transfer stream (TraceRays must wait for it)
+    double sums[RTH_MG_TIMES] = {};
+    int timedFrames = 0;
     std::string err;
 };
 
@@ -461,6 +484,25 @@ extern "C" {
 int rth_mg_band_bounds(int height, int world, int* out) {
     if (height < 1 || world < 1 || !out) return -1;
     for (int r = 0; r < world; r++) out[r] = (int)nearbyint((double)height * r / world / 8.0) * 8;  // round half to even
+    out[world] = height;
+    for (int r = 0; r < world; r++) if (out[r + 1] <= out[r]) return -1;
+    return 0;
+}
+// The same with a cost per row: bands of roughly equal cost, none shorter than minRows (a band must be at least as tall
+// as the halo its neighbours take from it).  The twin of multigpu.band_bounds(height, world, weights, min_rows).
+int rth_mg_balanced_bounds(int height, int world, const double* rowCost, int minRows, int* out) {
+    if (height < 1 || world < 1 || !out || !rowCost) return -1;
+    minRows = (std::max(minRows, 8) + 7) / 8 * 8;
+    std::vector<double> c((size_t)height + 1, 0.0);
+    for (int i = 0; i < height; i++) c[(size_t)i + 1] = c[(size_t)i] + rowCost[i];
+    out[0] = 0;
+    for (int r = 1; r < world; r++) {
+        const double want = c[(size_t)height] * r / world;
+        const int row = (int)(std::lower_bound(c.begin(), c.end(), want) - c.begin());
+        int cut = std::max(out[r - 1] + minRows, (int)nearbyint(row / 8.0) * 8);
+        cut = std::min(cut, (height - (world - r) * minRows) / 8 * 8);  // leave room for the bands below
+        out[r] = cut;
+    }
     out[world] = height;
     for (int r = 0; r < world; r++) if (out[r + 1] <= out[r]) return -1;
     return 0;
@@ -491,25 +533,31 @@ int rth_mg_unique_id(unsigned char out[128]) {
 }
 
 namespace {
+bool mgBoundsOk(rth_mg g, const int* b, std::string& why) {
+    bool ok = b[0] == 0 && b[g->world] == g->H;
+    for (int r = 0; r < g->world; r++) ok = ok && b[r + 1] > b[r] && (b[r] % 8 == 0);
+    if (!ok) { why = "band boundaries must start at 0, end at the image height, increase, and be multiples of 8"; return false; }
+    const int total = rth_mg_halo_plan(g->iterations, g->blur, nullptr, nullptr);
+    for (int r = 0; r < g->world; r++)
+        if (g->world > 1 && b[r + 1] - b[r] < total) { why = "a band is shorter than the halo: use fewer GPUs or a larger image"; return false; }
+    return true;
+}
 rth_mg mgCreate(rth_mg g, int rank, int world, const int* bounds, const unsigned char uniqueId[128], char* err, int errLen) {
     auto fail = [&](const std::string& msg) { if (err && errLen > 0) snprintf(err, (size_t)errLen, "%s", msg.c_str()); delete g; return (rth_mg) nullptr; };
     if (!g->ctx || world < 1 || rank < 0 || rank >= world) return fail("bad arguments");
     g->rank = rank; g->world = world;
     g->bounds.resize((size_t)world + 1);
-    if (bounds) {  // the caller's cuts (e.g. balanced by cost); every rank must pass the same ones
+    if (bounds) {  // the caller's cuts; every rank must pass the same ones
         for (int r = 0; r <= world; r++) g->bounds[(size_t)r] = bounds[r];
-        bool ok = bounds[0] == 0 && bounds[world] == g->H;
-        for (int r = 0; r < world; r++) ok = ok && bounds[r + 1] > bounds[r] && (bounds[r] % 8 == 0);
-        if (!ok) return fail("band boundaries must start at 0, end at the image height, increase, and be multiples of 8");
     } else if (rth_mg_band_bounds(g->H, world, g->bounds.data()) != 0) return fail("the image cannot be cut into that many bands of whole tiles");
-    const int total = rth_mg_halo_plan(g->iterations, g->blur, nullptr, nullptr);
-    for (int r = 0; r < world; r++)
-        if (world > 1 && g->bounds[(size_t)r + 1] - g->bounds[(size_t)r] < total) return fail("a band is shorter than the halo: use fewer GPUs or a larger image");
+    std::string why;
+    if (!mgBoundsOk(g, g->bounds.data(), why)) return fail(why);
     // A communicator of one rank is legal (and lets a single GPU exercise the set-up).  Several ranks WITHOUT an id
     // get no communicator: such a rank can only be stepped with rth_mg_phase / rth_mg_plan, by a test that carries
     // the transfers out itself.
     if (uniqueId) {
         if (!rccl().ok) return fail(rccl().why);
+        if (!rt_transfer_stream(g->ctx)) return fail(rt_last_error(g->ctx));
         Rccl::UniqueId id;
         memcpy(id.internal, uniqueId, 128);
         int rc = rccl().CommInitRank(&g->comm, world, id, rank);  // on the device current in this thread (rt_create made it so)
@@ -540,6 +588,7 @@ rth_mg rth_mg_create_ris(rth_ris_main m, int rank, int world, const int* bounds,
 void rth_mg_destroy(rth_mg g) {
     if (!g) return;
     if (g->comm) { rt_sync(g->ctx); rccl().CommDestroy(g->comm); }
+    rt_sync(g->ctx);
     rt_set_row_band(g->ctx, 0, 0);
     delete g;
 }
@@ -549,9 +598,17 @@ int rth_mg_bounds(rth_mg g, int* out) {
     for (size_t i = 0; i < g->bounds.size(); i++) out[i] = g->bounds[i];
     return 0;
 }
+int rth_mg_set_bounds(rth_mg g, const int* bounds) {
+    if (!g || !bounds) return -1;
+    std::string why;
+    if (!mgBoundsOk(g, bounds, why)) { g->err = why; return -1; }
+    for (int r = 0; r <= g->world; r++) g->bounds[(size_t)r] = bounds[r];
+    return 0;
+}
 
 // Self-test of the transfer path on one rank: rows [src0, src1) of the Candidates buffer and of the depth texture are
-// sent to, and received from, this same rank with the RCCL calls the frame loop uses, landing at row dst0.
+// sent to, and received from, this same rank with the RCCL calls the frame loop uses (on the transfer stream, ordered
+// after the kernels), landing at row dst0.
 int rth_mg_loopback(rth_mg g, int src0, int src1, int dst0) {
     if (!g || !g->m || !g->comm || src1 <= src0) return -1;
     rth_main m = g->m;
@@ -566,13 +623,16 @@ int rth_mg_loopback(rth_mg g, int src0, int src1, int dst0) {
         g->err = rt_last_error(ctx);
         return -1;
     }
+    void* stream = rt_transfer_stream(ctx);
+    if (!stream || rt_stream_order(ctx, 0) < 0) { g->err = rt_last_error(ctx); return -1; }
     int rc = rccl().GroupStart();
     for (int k = 0; k <= na && rc == 0; k++) {
-        rc = rccl().Send(a[k].ptr, a[k].bytes, NCCL_UINT8, g->rank, g->comm, rt_stream(ctx));
-        if (rc == 0) rc = rccl().Recv(b[k].ptr, b[k].bytes, NCCL_UINT8, g->rank, g->comm, rt_stream(ctx));
+        rc = rccl().Send(a[k].ptr, a[k].bytes, NCCL_UINT8, g->rank, g->comm, stream);
+        if (rc == 0) rc = rccl().Recv(b[k].ptr, b[k].bytes, NCCL_UINT8, g->rank, g->comm, stream);
     }
     int rc2 = rccl().GroupEnd();
     if (rc != 0 || rc2 != 0) { g->err = std::string("RCCL loopback: ") + rccl().GetErrorString(rc != 0 ? rc : rc2); return -1; }
+    if (rt_stream_order(ctx, 1) < 0) { g->err = rt_last_error(ctx); return -1; }
     return 0;
 }
 
@@ -621,51 +681,86 @@ void mgPlanGather(rth_mg g, std::vector<rth_xfer>& plan) {
         mgRows(g, plan, true, nullptr, result, g->bounds[(size_t)g->rank], g->bounds[(size_t)g->rank + 1], 0);
     }
 }
-// Phase 0 of a frame: everything before the halo exchange.  Phase 1: everything after it.
+// The rows of the first spatial pass that read nothing a neighbour owns: the band shrunk by that pass's halo on every
+// side that has a neighbour.
+void mgInterior(rth_mg g, int* lo, int* hi) {
+    const int b0 = g->bounds[(size_t)g->rank], b1 = g->bounds[(size_t)g->rank + 1];
+    int halo0 = 0;
+    if (g->iterations > 0) {
+        std::vector<int> halo((size_t)g->iterations);
+        rth_mg_halo_plan(g->iterations, g->blur, halo.data(), nullptr);
+        halo0 = halo[0];
+    }
+    *lo = g->rank > 0 ? b0 + halo0 : b0;
+    *hi = g->rank < g->world - 1 ? b1 - halo0 : b1;
+    if (*hi < *lo) *hi = *lo;
+}
+// A frame in four steps.  0: everything before the halo exchange (InitialTrace, TemporalReuse on the band).
+// 1: the first spatial pass on the interior rows (needs no halo).  2: the rest of the spatial reuse, which needs the
+// halos: the first pass on the border rows, the later passes, TransferToOriginal.  3: TraceRays and AccumulateFrames
+// (TraceRays writes this rank's band of Result, which the previous frame's gather may still be reading).
 void mgPhase(rth_mg g, int phase) {
     rth_main m = g->m;
     rt_ctx ctx = g->ctx;
     const int rank = g->rank, world = g->world, H = g->H;
     const int b0 = g->bounds[(size_t)rank], b1 = g->bounds[(size_t)rank + 1];
     auto rows = [&](int r0, int r1) { mgCheck(g, rt_set_row_band(ctx, r0, r1), "rt_set_row_band"); };
-    if (g->ris) {  // the whole RIS frame precedes its only transfer, the gather
-        if (phase != 0) return;
+    if (g->ris) {  // the RIS kernels read only their own pixel: no halo; TraceRays (with AccumulateFrames) is step 3
         auto ris = [&](int rc) { if (rc != 0) throw DriverError{rth_ris_main_last_error(g->ris)}; };
         rows(b0, b1);
-        ris(rth_ris_main_update_per_frame(g->ris));
-        ris(rth_ris_main_run_stage(g->ris, 0));
-        ris(rth_ris_main_run_stage(g->ris, 1));
-        ris(rth_ris_main_run_post_processing(g->ris));
+        if (phase == 0) { ris(rth_ris_main_update_per_frame(g->ris)); ris(rth_ris_main_run_stage(g->ris, 0)); }
+        if (phase == 3) { ris(rth_ris_main_run_stage(g->ris, 1)); ris(rth_ris_main_run_post_processing(g->ris)); }
         return;
     }
     m->CreateTextures();
-    if (phase == 0) {
-        rows(b0, b1);
-        m->UpdatePerFrame();
-        m->RunStage(0);
-        m->RunStage(1);
-        return;
-    }
     const int iterations = m->cfg.SpatialReuseIterations;
-    if (iterations > 0) {
-        std::vector<int> halo((size_t)iterations), extend((size_t)iterations);
-        rth_mg_halo_plan(iterations, m->cfg.SpatialReuseBlur, halo.data(), extend.data());
-        for (int i = 0; i < iterations; i++) {
-            // the earlier passes also write the rows the later passes will read from beyond the band
-            int lo = rank > 0 ? b0 - extend[(size_t)i] : b0, hi = rank < world - 1 ? b1 + extend[(size_t)i] : b1;
-            rows(lo > 0 ? lo : 0, hi < H ? hi : H);
-            m->SpatialReusePass(i);
+    int lo = b0, hi = b1;
+    mgInterior(g, &lo, &hi);
+    switch (phase) {
+        case 0:
+            rows(b0, b1);
+            m->UpdatePerFrame();
+            m->RunStage(0);
+            m->RunStage(1);
+            return;
+        case 1:
+            if (iterations > 0 && hi > lo) { rows(lo, hi); m->SpatialReusePass(0); }
+            return;
+        case 2: {
+            if (iterations <= 0) return;
+            std::vector<int> halo((size_t)iterations), extend((size_t)iterations);
+            rth_mg_halo_plan(iterations, m->cfg.SpatialReuseBlur, halo.data(), extend.data());
+            for (int i = 0; i < iterations; i++) {
+                // the earlier passes also write the rows the later passes will read from beyond the band
+                int wlo = rank > 0 ? b0 - extend[(size_t)i] : b0, whi = rank < world - 1 ? b1 + extend[(size_t)i] : b1;
+                wlo = wlo > 0 ? wlo : 0; whi = whi < H ? whi : H;
+                if (i == 0) {  // the interior rows are done: the two border strips remain
+                    if (lo > wlo) { rows(wlo, lo < whi ? lo : whi); m->SpatialReusePass(0); }
+                    if (whi > hi) { rows(hi > wlo ? hi : wlo, whi); m->SpatialReusePass(0); }
+                    if (hi <= lo && !(lo > wlo) && !(whi > hi)) { rows(wlo, whi); m->SpatialReusePass(0); }
+                } else {
+                    rows(wlo, whi);
+                    m->SpatialReusePass(i);
+                }
+            }
+            rows(b0, b1);
+            m->TransferIfNeeded();
+            return;
         }
-        rows(b0, b1);
-        m->TransferIfNeeded();
+        case 3:
+            rows(b0, b1);
+            m->RunStage(3);
+            m->RunPostProcessingShader();
+            return;
+        default: throw DriverError{"unknown phase"};
     }
-    m->RunStage(3);
-    m->RunPostProcessingShader();
 }
+// Enqueues the transfers of `plan` as one RCCL group on the transfer stream.
 void mgRun(rth_mg g, const std::vector<rth_xfer>& plan) {
     if (plan.empty()) return;
     auto nccl = [&](int rc, const char* what) { if (rc != 0) throw DriverError{std::string(what) + ": " + rccl().GetErrorString(rc)}; };
-    void* stream = rt_stream(g->ctx);
+    void* stream = rt_transfer_stream(g->ctx);
+    if (!stream) throw DriverError{rt_last_error(g->ctx)};
     nccl(rccl().GroupStart(), "ncclGroupStart");
     for (const auto& x : plan) {
         if (x.send) nccl(rccl().Send(x.ptr, x.bytes, NCCL_UINT8, x.peer, g->comm, stream), "ncclSend");
@@ -673,22 +768,72 @@ void mgRun(rth_mg g, const std::vector<rth_xfer>& plan) {
     }
     nccl(rccl().GroupEnd(), "ncclGroupEnd");
 }
+void mgMark(rth_mg g, int stream, int slot) {
+    if (g->timing) mgCheck(g, rt_mark(g->ctx, stream, slot), "rt_mark");
+}
+void mgOrder(rth_mg g, int first) { mgCheck(g, rt_stream_order(g->ctx, first), "rt_stream_order"); }
+double mgElapsed(rth_mg g, int a, int b) {
+    double ms = 0;
+    mgCheck(g, rt_mark_elapsed(g->ctx, a, b, &ms), "rt_mark_elapsed");
+    return ms;
+}
 
 }  // namespace
 
 extern "C" {
 
-// n banded frames, enqueued on the context's stream (asynchronous; rt_sync waits for them).
+// n banded frames, enqueued (asynchronous; rt_sync waits for them, both streams).
 int rth_mg_render_frames(rth_mg g, int n) {
     if (!g) return -1;
     if (g->world > 1 && !g->comm) { g->err = "this rank was created without a communicator"; return -1; }
     try {
         std::vector<rth_xfer> plan;
+        const bool multi = g->world > 1;
         for (int f = 0; f < n; f++) {
+            mgMark(g, 0, MK_FRAME);
             mgPhase(g, 0);
-            if (g->world > 1) { plan.clear(); mgPlanHalo(g, plan); mgRun(g, plan); }
+            mgMark(g, 0, MK_PRE);
+            if (multi) {  // the halos leave once the band's reservoirs exist, and travel beside the interior rows
+                plan.clear();
+                mgPlanHalo(g, plan);
+                mgOrder(g, 0);
+                mgMark(g, 1, MK_HALO0);
+                mgRun(g, plan);
+                mgMark(g, 1, MK_HALO1);
+            }
             mgPhase(g, 1);
-            if (g->world > 1) { plan.clear(); mgPlanGather(g, plan); mgRun(g, plan); }
+            mgMark(g, 0, MK_INTERIOR);
+            if (multi) mgOrder(g, 1);
+            mgPhase(g, 2);
+            mgMark(g, 0, MK_POST0);
+            // (mgOrder above already made the dispatch stream wait for everything on the transfer stream, the
+            // previous frame's gather included, so TraceRays may overwrite this rank's band of Result)
+            mgPhase(g, 3);
+            mgMark(g, 0, MK_END);
+            if (multi) {
+                plan.clear();
+                mgPlanGather(g, plan);
+                mgOrder(g, 0);
+                mgMark(g, 1, MK_GATHER0);
+                mgRun(g, plan);
+                mgMark(g, 1, MK_GATHER1);
+                g->gatherPending = true;
+            }
+            if (g->timing) {  // reading the stamps waits for the frame: timing mode gives up the overlap between frames
+                g->sums[RTH_MG_T_FRAME] += mgElapsed(g, MK_FRAME, MK_END);
+                g->sums[RTH_MG_T_BEFORE_HALO] += mgElapsed(g, MK_FRAME, MK_PRE);
+                g->sums[RTH_MG_T_INTERIOR] += mgElapsed(g, MK_PRE, MK_INTERIOR);
+                g->sums[RTH_MG_T_AFTER_HALO] += mgElapsed(g, MK_INTERIOR, MK_END);
+                if (multi) {
+                    g->sums[RTH_MG_T_HALO] += mgElapsed(g, MK_HALO0, MK_HALO1);
+                    g->sums[RTH_MG_T_GATHER] += mgElapsed(g, MK_GATHER0, MK_GATHER1);
+                    // how long the dispatch stream stood still for the halos: from the end of the interior rows to
+                    // the arrival of the last halo row, if that came later
+                    const double wait = mgElapsed(g, MK_INTERIOR, MK_HALO1);
+                    g->sums[RTH_MG_T_HALO_EXPOSED] += wait > 0 ? wait : 0;
+                }
+                g->timedFrames++;
+            }
         }
     } catch (const DriverError& e) {
         g->err = e.msg;
@@ -696,10 +841,22 @@ int rth_mg_render_frames(rth_mg g, int n) {
     }
     return 0;
 }
-// The two halves of a frame and the transfer lists between them, one at a time: lets a test that holds several ranks
-// in one process (all on one GPU, no communicator) carry the transfers out itself and so check the schedule.
+int rth_mg_enable_timing(rth_mg g, int on) {
+    if (!g) return -1;
+    g->timing = on != 0;
+    for (double& s : g->sums) s = 0;
+    g->timedFrames = 0;
+    return 0;
+}
+int rth_mg_times(rth_mg g, double out[RTH_MG_TIMES]) {
+    if (!g || !out) return -1;
+    for (int i = 0; i < RTH_MG_TIMES; i++) out[i] = g->timedFrames ? g->sums[i] / g->timedFrames : 0.0;
+    return g->timedFrames;
+}
+// The steps of a frame and the transfer lists between them, one at a time: lets a test that holds several ranks in one
+// process (all on one GPU, no communicator) carry the transfers out itself and so check the schedule.
 int rth_mg_phase(rth_mg g, int phase) {
-    if (!g || phase < 0 || phase > 1) return -1;
+    if (!g || phase < 0 || phase > 3) return -1;
     try { mgPhase(g, phase); } catch (const DriverError& e) { g->err = e.msg; return -1; }
     return 0;
 }
@@ -713,6 +870,64 @@ int rth_mg_plan(rth_mg g, int which, rth_xfer* out, int cap) {
     if ((int)plan.size() > cap || (!out && !plan.empty())) return -1;
     for (size_t i = 0; i < plan.size(); i++) out[i] = plan[i];
     return (int)plan.size();
+}
+
+// Cost-balanced bands without a frame rendered in full: this rank renders the primary rays of frame 0 on its present
+// band (what the real frame 0 will render again, so nothing is disturbed), reads the band's depth back and writes
+// 1 + 24 per hit pixel for each of its rows into rowCost[H] (0 for the rows of other ranks).  The frame counters are
+// put back, so the first rth_mg_render_frames still renders frame 0.
+int rth_mg_row_costs(rth_mg g, double* rowCost) {
+    if (!g || !rowCost || !g->m) return -1;
+    rth_main m = g->m;
+    try {
+        const int b0 = g->bounds[(size_t)g->rank], b1 = g->bounds[(size_t)g->rank + 1];
+        m->CreateTextures();
+        mgCheck(g, rt_set_row_band(g->ctx, b0, b1), "rt_set_row_band");
+        const int fc = m->FrameCount, fs = m->framesStarted;
+        m->UpdatePerFrame();
+        m->RunStage(0);
+        m->FrameCount = fc; m->framesStarted = fs;
+        std::vector<float> depth((size_t)(b1 - b0) * g->W);
+        mgCheck(g, rt_texture_get_rows(m->DepthBufferTexture.h, depth.data(), b0, b1), "rt_texture_get_rows");
+        for (int y = 0; y < g->H; y++) rowCost[y] = 0.0;
+        for (int y = b0; y < b1; y++) {
+            int hits = 0;
+            for (int x = 0; x < g->W; x++) hits += std::isfinite(depth[(size_t)(y - b0) * g->W + x]) ? 1 : 0;
+            rowCost[y] = (double)g->W + 24.0 * hits;   // multigpu.row_cost
+        }
+    } catch (const DriverError& e) { g->err = e.msg; return -1; }
+    return 0;
+}
+// Collective: every rank measures its rows (rth_mg_row_costs), the vectors are summed over the ranks with one
+// ncclAllReduce of H doubles, and every rank derives the same balanced cuts from the sum.
+int rth_mg_balance(rth_mg g) {
+    if (!g || !g->m) return -1;
+    if (g->world == 1) return 0;
+    if (!g->comm) { g->err = "this rank was created without a communicator"; return -1; }
+    std::vector<double> cost((size_t)g->H);
+    if (rth_mg_row_costs(g, cost.data()) != 0) return -1;
+    rt_buffer buf = nullptr;
+    int rc = -1;
+    try {
+        mgCheck(g, rt_buffer_create(g->ctx, g->H, 8, &buf), "rt_buffer_create");
+        mgCheck(g, rt_buffer_set_data(buf, cost.data(), cost.size() * 8), "rt_buffer_set_data");
+        rt_segment seg[4];
+        int cnt = 0;
+        mgCheck(g, rt_buffer_map_rows(buf, 1, 0, g->H, seg, &cnt), "rt_buffer_map_rows");
+        void* stream = rt_transfer_stream(g->ctx);
+        if (!stream) throw DriverError{rt_last_error(g->ctx)};
+        mgOrder(g, 0);
+        int nrc = rccl().AllReduce(seg[0].ptr, seg[0].ptr, (size_t)g->H, NCCL_DOUBLE, NCCL_SUM, g->comm, stream);
+        if (nrc != 0) throw DriverError{std::string("ncclAllReduce: ") + rccl().GetErrorString(nrc)};
+        mgOrder(g, 1);
+        mgCheck(g, rt_buffer_get_data(buf, cost.data(), cost.size() * 8), "rt_buffer_get_data");
+        std::vector<int> b((size_t)g->world + 1);
+        const int total = rth_mg_halo_plan(g->iterations, g->blur, nullptr, nullptr);
+        if (rth_mg_balanced_bounds(g->H, g->world, cost.data(), total, b.data()) != 0) throw DriverError{"no balanced cuts exist for this image"};
+        rc = rth_mg_set_bounds(g, b.data());
+    } catch (const DriverError& e) { g->err = e.msg; rc = -1; }
+    rt_buffer_release(buf);
+    return rc;
 }
 
 }  // extern "C"

@@ -177,10 +177,14 @@ rt_shader rth_main_shader(rth_main m, const char* name); /* "rt", "pp", "pc" */
 /* ------------------------------------------- multi-GPU frame loop --------------------------------------- */
 /* One process per GPU; the image is cut into row bands (rt_set_row_band), the scene replicated, reservoir/depth
  * halos exchanged once per frame and the displayed image completed on rank 0 with RCCL point-to-point transfers on
- * the context's stream.  No counterpart in the reference, which is single-GPU. */
+ * the context's transfer stream (rt_transfer_stream), beside the kernels: the halos travel while the first spatial
+ * pass runs on the rows that need none, the gather of frame f while frame f+1 traces its primary rays.  No
+ * counterpart in the reference, which is single-GPU. */
 typedef struct rth_mg_s* rth_mg;
 /* Band boundaries b[0..world] (multiples of 8 rows except the last).  -1 if a band would be empty. */
 int rth_mg_band_bounds(int height, int world, int* out);
+/* The same from a cost per row: bands of about equal cost, none shorter than minRows. */
+int rth_mg_balanced_bounds(int height, int world, const double* rowCost, int minRows, int* out);
 /* halo[i] / extend[i] per spatial pass (see the definition); returns the rows exchanged per frame. */
 int rth_mg_halo_plan(int iterations, int blur, int* halo, int* extend);
 /* ncclGetUniqueId on the calling rank; the 128 bytes must reach every rank (any side channel) before rth_mg_create. */
@@ -193,19 +197,37 @@ rth_mg rth_mg_create(rth_main m, int rank, int world, const int* bounds, const u
 void rth_mg_destroy(rth_mg g);
 const char* rth_mg_last_error(rth_mg g);
 int rth_mg_bounds(rth_mg g, int* out);
+/* New cuts (before the first frame, the same on every rank). */
+int rth_mg_set_bounds(rth_mg g, const int* bounds);
+/* Cost-balanced cuts.  rth_mg_row_costs: this rank traces the primary rays of frame 0 on its present band (the real
+ * frame 0 repeats them; the frame counters are put back) and writes a cost per row for its own rows into rowCost[H],
+ * 0 elsewhere.  rth_mg_balance (collective, needs a communicator): sums those vectors over the ranks with one
+ * ncclAllReduce and sets the cuts rth_mg_balanced_bounds derives from the sum.  Call before the first frame. */
+int rth_mg_row_costs(rth_mg g, double* rowCost);
+int rth_mg_balance(rth_mg g);
 /* Self-test: moves rows [src0, src1) of Candidates and DepthBuffer to row dst0 through RCCL send/recv addressed to
  * this same rank (needs a communicator, i.e. a unique id at creation). */
 int rth_mg_loopback(rth_mg g, int src0, int src1, int dst0);
 /* One transfer of a frame's exchange: bytes at ptr (device memory of this rank) sent to, or received from, peer. */
 typedef struct { int32_t send; int32_t peer; void* ptr; size_t bytes; } rth_xfer;
-/* A frame in steps, for tests that hold several ranks in one process and move the data themselves: phase 0 = the
- * dispatches before the halo exchange, phase 1 = those after it; plan 0 = the halo exchange, plan 1 = the gather of
- * the displayed image, as the lists of transfers rth_mg_render_frames would hand to RCCL, in order.  rth_mg_plan
- * returns the number of entries, or -1. */
+/* A frame in steps, for tests that hold several ranks in one process and move the data themselves.
+ * Phases: 0 = InitialTrace and TemporalReuse on the band; 1 = the first spatial pass on the rows that need no halo;
+ * 2 = the rest of the spatial reuse (needs the halos); 3 = TraceRays and AccumulateFrames.
+ * Plans: 0 = the halo exchange (may be carried out any time between phase 0 and phase 2), 1 = the gather of the
+ * displayed image (any time between phase 3 and the next frame's phase 3), as the lists of transfers
+ * rth_mg_render_frames hands to RCCL, in order.  rth_mg_plan returns the number of entries, or -1. */
 int rth_mg_phase(rth_mg g, int phase);
 int rth_mg_plan(rth_mg g, int which, rth_xfer* out, int cap);
 /* Enqueues n banded frames (asynchronous).  After rt_sync, rank 0's Result texture holds the whole image. */
 int rth_mg_render_frames(rth_mg g, int n);
+/* Per-frame breakdown, averaged over the frames rendered since timing was switched on (each frame is then waited
+ * for, so frames no longer overlap): milliseconds on the dispatch stream for the whole frame, before the halo
+ * exchange, for the interior rows of the first spatial pass and for everything after; on the transfer stream for the
+ * halo exchange and the gather; and the part of the halo exchange the dispatch stream had to wait for. */
+enum { RTH_MG_T_FRAME = 0, RTH_MG_T_BEFORE_HALO, RTH_MG_T_INTERIOR, RTH_MG_T_AFTER_HALO, RTH_MG_T_HALO, RTH_MG_T_HALO_EXPOSED,
+       RTH_MG_T_GATHER, RTH_MG_TIMES };
+int rth_mg_enable_timing(rth_mg g, int on);
+int rth_mg_times(rth_mg g, double out[RTH_MG_TIMES]);   /* returns the number of frames averaged */
 
 /* ------------------------------------- frame driver of the RIS project ---------------------------------- */
 typedef struct rth_ris_main_s* rth_ris_main;

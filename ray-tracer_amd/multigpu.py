@@ -131,11 +131,23 @@ def halo_plan(iterations, blur):
     return halos, extend, sum(halos)
 
 
+def interior_rows(rank, world, bounds, iterations, blur):
+    """Rows of the first spatial pass that read nothing a neighbour owns: the band shrunk by that pass's halo on every
+    side that has a neighbour (the twin of mgInterior in host/frame_driver.cpp)."""
+    b0, b1 = bounds[rank], bounds[rank + 1]
+    halo0 = spatial_halo(max_offset_of_pass(0, blur)) if iterations > 0 else 0
+    lo = b0 + halo0 if rank > 0 else b0
+    hi = b1 - halo0 if rank < world - 1 else b1
+    return lo, max(hi, lo)
+
+
 def render_frame_banded(stages, store, rank, world, bounds, height, iterations, blur):
     """One frame of the ReSTIR sequence on this rank's band, one halo exchange and one gather.
 
     `stages` provides the compute: update_per_frame(), set_rows(r0, r1), initial_trace(), temporal_reuse(),
-    spatial_pass(i), transfer(), trace_rays(), accumulate(); they act on the rows last given to set_rows."""
+    spatial_pass(i), transfer(), trace_rays(), accumulate(); they act on the rows last given to set_rows.
+    The order is the native loop's (host/frame_driver.cpp): the first spatial pass runs on the interior rows BEFORE the
+    halos are exchanged (natively: while they travel), on the border rows after."""
     b0, b1 = bounds[rank], bounds[rank + 1]
     stages.set_rows(b0, b1)
     stages.update_per_frame()
@@ -143,13 +155,27 @@ def render_frame_banded(stages, store, rank, world, bounds, height, iterations, 
     stages.temporal_reuse()
     if iterations > 0:
         _, extend, total = halo_plan(iterations, blur)
+        lo, hi = interior_rows(rank, world, bounds, iterations, blur)
+        if hi > lo:
+            stages.set_rows(lo, hi)
+            stages.spatial_pass(0)
         _exchange(store, ["DepthBuffer", "Candidates"], rank, world, bounds, total, height)
         for i in range(iterations):
             # never widen past the image, nor past the rows whose inputs were received
-            lo = b0 - extend[i] if rank > 0 else b0
-            hi = b1 + extend[i] if rank < world - 1 else b1
-            stages.set_rows(max(lo, 0), min(hi, height))
-            stages.spatial_pass(i)
+            wlo = max(b0 - extend[i] if rank > 0 else b0, 0)
+            whi = min(b1 + extend[i] if rank < world - 1 else b1, height)
+            if i == 0:
+                if hi <= lo:
+                    strips = [(wlo, whi)]
+                else:
+                    strips = [(wlo, min(lo, whi)), (max(hi, wlo), whi)]
+                for s0, s1 in strips:
+                    if s1 > s0:
+                        stages.set_rows(s0, s1)
+                        stages.spatial_pass(0)
+            else:
+                stages.set_rows(wlo, whi)
+                stages.spatial_pass(i)
         stages.set_rows(b0, b1)
     stages.transfer()
     stages.trace_rays()
@@ -300,6 +326,18 @@ def native_halo_plan(iterations, blur):
     return list(halo)[:iterations], list(extend)[:iterations], total
 
 
+def native_balanced_bounds(height, world, weights, min_rows):
+    """rth_mg_balanced_bounds: the C++ twin of band_bounds(height, world, weights, min_rows)."""
+    import ctypes as C
+    import importlib
+    host = importlib.import_module("ray-tracer_amd").host_lib()
+    w = (C.c_double * height)(*[float(x) for x in weights])
+    out = (C.c_int * (world + 1))()
+    if host.rth_mg_balanced_bounds(height, world, w, min_rows, out) != 0:
+        raise ValueError(f"image of {height} rows cannot be cut into {world} non-empty bands of whole tiles")
+    return list(out)
+
+
 class RcclRunner:
     """One rank of the native multi-GPU frame loop (host/frame_driver.cpp: rth_mg_*): the banded schedule above, run
     from C++ with RCCL send/recv on the library's stream, so no Python runs between the dispatches of a frame.
@@ -314,33 +352,36 @@ class RcclRunner:
         self.ris = isinstance(cfg, rt.RisConfig)
         self.drv = rt.RisDriver(self.ctx, cfg, scene) if self.ris else rt.Driver(self.ctx, cfg, scene)
         self.W, self.H = cfg.Resolution[0], cfg.Resolution[1]
-        bounds = None
-        if balance and world > 1 and not self.ris:
-            # Frame 0 is rendered in full by every rank: all ranks then hold the same depth buffer, derive the same
-            # per-row cost from it and so agree on cost-balanced bands without exchanging anything; the frames that
-            # follow are banded and continue the same sequence a single GPU would render.
-            self.drv.render_frame()
-            self.ctx.sync()
-            _, _, total = halo_plan(cfg.SpatialReuseIterations, cfg.SpatialReuseBlur)
-            bounds = band_bounds(self.H, world, row_cost(self.drv.texture("DepthBuffer")), min_rows=total)
-        uid = None
+        # Every rank takes part in the id broadcast whatever happened on rank 0 (a rank that raised before it would
+        # leave the others waiting in it): rank 0 sends the id, or the reason it has none, and all ranks raise together.
+        uid, why = None, ""
         if world > 1 or force_comm:
             buf = C.create_string_buffer(128)
-            if rank == 0 and self.host.rth_mg_unique_id(buf) != 0:
-                raise RuntimeError("ncclGetUniqueId failed (is librccl.so loadable?)")
-            uid = buf.raw
+            if rank == 0:
+                if self.host.rth_mg_unique_id(buf) == 0:
+                    uid = buf.raw
+                else:
+                    why = "ncclGetUniqueId failed (is librccl.so loadable?)"
             if world > 1:
                 if not dist.is_initialized():
                     dist.init_process_group("gloo", rank=rank, world_size=world)
-                box = [uid]
+                box = [(uid, why)]
                 dist.broadcast_object_list(box, src=0)
-                uid = box[0]
+                uid, why = box[0]
+            if uid is None:
+                self.drv.close()
+                self.ctx.close()
+                raise RuntimeError(why or "no RCCL unique id")
         err = C.create_string_buffer(512)
-        cb = (C.c_int * (world + 1))(*bounds) if bounds else None
         create = self.host.rth_mg_create_ris if self.ris else self.host.rth_mg_create
-        self.h = create(self.drv.h, rank, world, cb, uid, err, 512)
+        self.h = create(self.drv.h, rank, world, None, uid, err, 512)
         if not self.h:
             raise RuntimeError("rth_mg_create: " + err.value.decode())
+        if balance and world > 1 and not self.ris:
+            # cost-balanced bands: each rank traces the primary rays of its equal-height band once, the per-row costs are
+            # summed over the ranks with one small all-reduce, and all ranks derive the same cuts (rth_mg_balance)
+            if self.host.rth_mg_balance(self.h) != 0:
+                raise RuntimeError("rth_mg_balance: " + self.host.rth_mg_last_error(self.h).decode())
         b = (C.c_int * (world + 1))()
         self.host.rth_mg_bounds(self.h, b)
         self.bounds = list(b)
@@ -371,6 +412,23 @@ class RcclRunner:
 
     def band_pixels(self):
         return (self.bounds[self.rank + 1] - self.bounds[self.rank]) * self.W
+
+    TIME_NAMES = ("frame", "before_halo", "interior_rows", "after_halo", "halo_exchange", "halo_exposed", "gather")
+
+    def timed_frames(self, n):
+        """Renders n frames with the per-frame stamps on (each frame is waited for) and returns the average milliseconds
+        of rth_mg_times: dispatch-stream time of the frame and of its parts, transfer-stream time of the halo exchange
+        and of the gather, and the part of the halo exchange the dispatch stream waited for."""
+        import ctypes as C
+        self.host.rth_mg_enable_timing(self.h, 1)
+        try:
+            self.render_frames(n)
+            self.sync()
+            out = (C.c_double * len(self.TIME_NAMES))()
+            self.host.rth_mg_times(self.h, out)
+        finally:
+            self.host.rth_mg_enable_timing(self.h, 0)
+        return {k: float(v) for k, v in zip(self.TIME_NAMES, out)}
 
     def close(self):
         if self.h:

@@ -76,7 +76,9 @@ def test_native_frame_loop_single_rank(gpu_ctx, scene_small):
     runner = mg.RcclRunner(rt, scene_small, cfg, 0, 1, 0, force_comm=True)
     try:
         assert runner.bounds == [0, 96]
-        runner.render_frames(2)
+        runner.render_frames(1)
+        t = runner.timed_frames(1)
+        assert t["frame"] > 0 and t["halo_exchange"] == 0 and t["gather"] == 0 and t["before_halo"] + t["interior_rows"] + t["after_halo"] <= t["frame"] * 1.05
         runner.render_frame()
         runner.sync()
         for n in want:
@@ -96,13 +98,16 @@ def test_native_frame_loop_single_rank(gpu_ctx, scene_small):
         runner.close()
 
 
-@pytest.mark.parametrize("world,res,balanced", [(2, (128, 96), False), (3, (96, 160), True), (8, (64, 384), False)])
+@pytest.mark.parametrize("world,res,balanced", [(2, (128, 96), False), (3, (96, 160), True), (8, (64, 384), False), (2, (64, 96), False)])
 def test_native_schedule_many_ranks_in_process(scene_small, world, res, balanced):
     """The C++ banded schedule for 2, 3 and 8 ranks, all held in this process on the one GPU: each rank is stepped
-    through the two halves of a frame (rth_mg_phase) and the transfer lists the frame loop would hand to RCCL
+    through the four steps of a frame (rth_mg_phase) and the transfer lists the frame loop would hand to RCCL
     (rth_mg_plan) are carried out here with device-to-device copies, the k-th send of rank a to rank b matched with
-    the k-th receive of rank b from rank a, as RCCL matches them.  Rank 0's gathered image and every rank's band
-    must equal the single-GPU render bit for bit over several frames."""
+    the k-th receive of rank b from rank a, as RCCL matches them.  The copies are made as LATE as the native loop's
+    stream ordering allows: the halos after the first spatial pass has run on the interior rows, the gather of a frame
+    after the next frame's spatial reuse, just before its TraceRays.  Rank 0's gathered image and every rank's band
+    must equal the single-GPU render bit for bit over several frames.  (The last case has bands of 48 rows, barely
+    more than the 42 halo rows: the spatial passes of each rank recompute most of its neighbour's band.)"""
     import ctypes as C
     import harness as h
     rt = h.rt
@@ -114,9 +119,6 @@ def test_native_schedule_many_ranks_in_process(scene_small, world, res, balanced
     W, H = res
     cfg = h.small_config(W, H)
     host = rt.host_lib()
-    bounds = None
-    if balanced:  # uneven cuts, as the cost balancer would produce
-        bounds = [0, 48, 104, H]
     ctxs = [rt.RtContext(0) for _ in range(world + 1)]
     drvs = [rt.Driver(c, cfg, scene_small) for c in ctxs]
     ref_ctx, ref = ctxs[world], drvs[world]
@@ -124,23 +126,40 @@ def test_native_schedule_many_ranks_in_process(scene_small, world, res, balanced
     err = C.create_string_buffer(512)
     try:
         for r in range(world):
-            cb = (C.c_int * (world + 1))(*bounds) if bounds else None
-            g = host.rth_mg_create(drvs[r].h, r, world, cb, None, err, 512)
+            g = host.rth_mg_create(drvs[r].h, r, world, None, None, err, 512)
             assert g, err.value.decode()
             ranks.append(g)
+        _, _, total = mg.native_halo_plan(cfg.SpatialReuseIterations, cfg.SpatialReuseBlur)
+        if balanced:
+            # what rth_mg_balance does, with the all-reduce made here: each rank measures its own rows, the vectors
+            # are summed, every rank derives the same cuts from the sum
+            summed = np.zeros(H)
+            for g in ranks:
+                mine = (C.c_double * H)()
+                assert host.rth_mg_row_costs(g, mine) == 0, host.rth_mg_last_error(g)
+                summed += np.array(mine)
+            assert (summed >= W).all() and summed.max() > W      # every row measured by exactly one rank, some rows hit
+            cuts = mg.native_balanced_bounds(H, world, summed, total)
+            assert cuts == mg.band_bounds(H, world, summed, total) and cuts != mg.band_bounds(H, world)
+            for g in ranks:
+                assert host.rth_mg_set_bounds(g, (C.c_int * (world + 1))(*cuts)) == 0, host.rth_mg_last_error(g)
+            assert host.rth_mg_set_bounds(ranks[0], (C.c_int * (world + 1))(*([0, 8, 16, H][:world + 1]))) != 0   # shorter than the halo
         b = (C.c_int * (world + 1))()
         host.rth_mg_bounds(ranks[0], b)
         cuts = list(b)
         # a rank without a communicator cannot run the RCCL loop
         assert host.rth_mg_render_frames(ranks[0], 1) != 0
 
-        def exchange(which):
+        def plan(which):
             plans = []
             for g in ranks:
                 buf = (bindings.Xfer * 64)()
                 n = host.rth_mg_plan(g, which, buf, 64)
                 assert n >= 0, host.rth_mg_last_error(g)
                 plans.append([buf[i] for i in range(n)])
+            return plans
+
+        def carry_out(plans):
             for c in ctxs[:world]:
                 c.sync()
             moved = 0
@@ -148,37 +167,45 @@ def test_native_schedule_many_ranks_in_process(scene_small, world, res, balanced
                 for bb in range(world):
                     sends = [x for x in plans[a] if x.send and x.peer == bb]
                     recvs = [x for x in plans[bb] if not x.send and x.peer == a]
-                    assert len(sends) == len(recvs), (which, a, bb)
+                    assert len(sends) == len(recvs), (a, bb)
                     for s, d in zip(sends, recvs):
                         assert s.bytes == d.bytes and s.bytes > 0
                         assert hip.hipMemcpy(d.ptr, s.ptr, s.bytes, 3) == 0
                         moved += s.bytes
             return moved
 
+        def phase(k):
+            for g in ranks:
+                assert host.rth_mg_phase(g, k) == 0, host.rth_mg_last_error(g)
+
+        gather, want_image = None, None
         for frame in range(3):
-            for g in ranks:
-                assert host.rth_mg_phase(g, 0) == 0, host.rth_mg_last_error(g)
-            halo_bytes = exchange(0)
-            for g in ranks:
-                assert host.rth_mg_phase(g, 1) == 0, host.rth_mg_last_error(g)
-            gather_bytes = exchange(1)
+            phase(0)
+            halo = plan(0)
+            phase(1)                            # the interior rows of the first pass: before any halo has arrived
+            halo_bytes = carry_out(halo)
+            phase(2)
+            if gather is not None:              # the previous frame's image arrives only now
+                assert carry_out(gather) == (H - cuts[1]) * W * 16
+                assert np.array_equal(h.bits(drvs[0].texture("Result")[cuts[1]:]), h.bits(want_image[cuts[1]:])), frame - 1
+            phase(3)
+            gather = plan(1)
             for c in ctxs[:world]:
                 c.sync()
             ref.render_frame()
             ref_ctx.sync()
-            want = ref.texture("Result")
-            assert np.array_equal(h.bits(drvs[0].texture("Result")), h.bits(want)), frame
+            want_image = ref.texture("Result")
             for r in range(world):
                 lo, hi = cuts[r], cuts[r + 1]
                 for name in ("Result", "AccumulatedResult", "DepthBuffer"):
                     assert np.array_equal(h.bits(drvs[r].texture(name)[lo:hi]), h.bits(ref.texture(name)[lo:hi])), (frame, r, name)
-                for name in ("Candidates", "TemporalFrameBuffer", "HitInfos"):
+                for name in ("Candidates", "CandidatesB", "TemporalFrameBuffer", "HitInfos"):
                     assert np.array_equal(h.bits(drvs[r].buffer(name)[lo * W:hi * W]), h.bits(ref.buffer(name)[lo * W:hi * W])), (frame, r, name)
-            # volume: every interior cut carries `total` rows each way of the reservoir planes and a 4-byte depth
-            _, _, total = mg.native_halo_plan(cfg.SpatialReuseIterations, cfg.SpatialReuseBlur)
+            # volume: every interior cut carries `total` rows each way of the reservoir records and a 4-byte depth
             per_pixel, rest = divmod(halo_bytes, 2 * (world - 1) * total * W)
             assert rest == 0 and 52 + 4 <= per_pixel <= 64 + 4, halo_bytes
-            assert gather_bytes == (H - cuts[1]) * W * 16
+        carry_out(gather)
+        assert np.array_equal(h.bits(drvs[0].texture("Result")), h.bits(want_image))
     finally:
         for g in ranks:
             host.rth_mg_destroy(g)
@@ -190,8 +217,9 @@ def test_native_schedule_many_ranks_in_process(scene_small, world, res, balanced
 
 @pytest.mark.parametrize("world,res", [(2, (64, 48)), (5, (96, 120))])
 def test_native_ris_schedule_many_ranks_in_process(scene_small, world, res):
-    """The banded RIS frame loop (rth_mg_create_ris) for several ranks held in this process: phase 0 renders the
-    band, plan 0 (the halo) is empty, plan 1 is the gather of Result, carried out here with device copies."""
+    """The banded RIS frame loop (rth_mg_create_ris) for several ranks held in this process: phase 0 generates the
+    band's candidates, phase 3 traces and accumulates, plan 0 (the halo) is empty, plan 1 is the gather of Result,
+    carried out here with device copies."""
     import ctypes as C
     import harness as h
     rt = h.rt
@@ -221,7 +249,8 @@ def test_native_ris_schedule_many_ranks_in_process(scene_small, world, res):
             for g in ranks:
                 assert host.rth_mg_phase(g, 0) == 0, host.rth_mg_last_error(g)
                 assert host.rth_mg_plan(g, 0, None, 0) == 0
-                assert host.rth_mg_phase(g, 1) == 0
+                assert host.rth_mg_phase(g, 1) == 0 and host.rth_mg_phase(g, 2) == 0     # nothing to do: no spatial reuse
+                assert host.rth_mg_phase(g, 3) == 0, host.rth_mg_last_error(g)
                 buf = (bindings.Xfer * 16)()
                 n = host.rth_mg_plan(g, 1, buf, 16)
                 assert n == (world - 1 if g is ranks[0] else 1), host.rth_mg_last_error(g)

@@ -179,3 +179,77 @@ def test_native_plan_matches_python():
         for blur in (1, 2, 3, 5):
             halos, extend, total = mg.halo_plan(iterations, blur)
             assert mg.native_halo_plan(iterations, blur) == (halos, extend, total), (iterations, blur)
+    # cost-balanced cuts: the C++ routine every rank runs on the summed per-row costs against the Python one
+    rng = np.random.default_rng(5)
+    for height, world, min_rows in ((1080, 8, 42), (2160, 8, 42), (1080, 3, 8), (400, 4, 14), (2160, 5, 30)):
+        for trial in range(6):
+            w = rng.random(height) ** 4 * (1 + 24 * 1920)
+            w[: rng.integers(0, height // 2)] = 1920.0                   # a run of sky rows
+            assert mg.native_balanced_bounds(height, world, w, min_rows) == mg.band_bounds(height, world, w, min_rows), (height, world, trial)
+    with pytest.raises(ValueError):
+        mg.native_balanced_bounds(64, 4, np.ones(64), 42)
+
+
+def test_interior_rows():
+    mg = importlib.import_module("ray-tracer_amd.multigpu")
+    b = [0, 136, 272, 408]
+    assert mg.interior_rows(0, 3, b, 3, 3) == (0, 132)      # no neighbour above: the band's first rows need no halo
+    assert mg.interior_rows(1, 3, b, 3, 3) == (140, 268)
+    assert mg.interior_rows(2, 3, b, 3, 3) == (276, 408)
+    assert mg.interior_rows(1, 3, [0, 8, 12, 400], 3, 3) == (12, 12)   # a band shorter than two halos has no interior
+    assert mg.interior_rows(0, 1, [0, 100], 3, 3) == (0, 100)
+
+
+class _FakeHost:
+    """Stands in for librthost.so in the test below: no RCCL on rank 0."""
+    def rth_mg_unique_id(self, buf):
+        return -1
+
+
+def _uid_failure_worker(rank, world, port, out_dir):
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    sys.path.insert(0, ROOT)
+    mg = importlib.import_module("ray-tracer_amd.multigpu")
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    try:
+        class Rt:   # just enough of the package for RcclRunner.__init__ to reach the id exchange
+            RisConfig = type("RisConfig", (), {})
+
+            @staticmethod
+            def host_lib():
+                return _FakeHost()
+
+            class RtContext:
+                def __init__(self, dev):
+                    pass
+
+                def close(self):
+                    pass
+
+            class Driver:
+                def __init__(self, ctx, cfg, scene):
+                    self.h = None
+
+                def close(self):
+                    pass
+
+        cfg = type("Cfg", (), {"Resolution": [64, 64]})()
+        try:
+            mg.RcclRunner(Rt, None, cfg, rank, world, 0)
+            raised = ""
+        except RuntimeError as e:
+            raised = str(e)
+        assert "ncclGetUniqueId failed" in raised, raised   # the SAME error on every rank, and nobody is left waiting
+        ok = torch.tensor([1])
+        dist.all_reduce(ok)                                 # the collective sequence is still in step
+        assert int(ok[0]) == world
+        open(os.path.join(out_dir, f"ok{rank}"), "w").write("ok")
+    finally:
+        dist.destroy_process_group()
+
+
+def test_unique_id_failure_reaches_every_rank(tmp_path):
+    """If rank 0 cannot make the RCCL id (librccl missing), every rank must learn it from the broadcast and raise; a
+    rank 0 that raised before the broadcast would leave the others blocked in it."""
+    mp.spawn(_uid_failure_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    assert all((tmp_path / f"ok{r}").exists() for r in range(2))
