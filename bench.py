@@ -70,17 +70,37 @@ def algorithmic_bytes(kernel, c, npx_launch):
     return 0
 
 
-def pmc_traffic(kernel, W, H, world, small_scene, scene="80k"):
-    """HBM bytes per launch of `kernel` from the committed PMC passes (FETCH_SIZE and WRITE_SIZE, one rocprofv3 --pmc
-    run each over this same command; tools/pmc_pass.sh, tools/pmc_to_traffic.py), or None when this run is not the
-    configuration they were collected on.  Counters cannot be read from inside the process being timed."""
-    if (W, H, world, small_scene, scene) != (1920, 1080, 1, False, "80k"):
-        return None
-    path = os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")
-    if not os.path.exists(path):
-        return None
-    k = json.load(open(path))["kernels"].get(kernel)
-    return k["hbm_bytes_per_launch"] if k else None
+def source_hash():
+    """Hash of the sources the GPU library is built from: the committed PMC figures are only quoted for the build they
+    were collected on."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    files = sorted(glob.glob(os.path.join(ROOT, "ray-tracer_amd", "csrc", "*")) + glob.glob(os.path.join(ROOT, "include", "*.h")))
+    for f in files:
+        h.update(os.path.relpath(f, ROOT).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
+PMC_FILE = os.path.join(ROOT, "profiles", "r02_pmc.json")
+
+
+def pmc_profile(W, H, world, small_scene, scene, project):
+    """(per-kernel PMC figures, None) from the committed rocprofv3 --pmc passes over this same command
+    (tools/collect_profiles.sh -> tools/make_pmc_profile.py), or (None, reason) when they do not describe this run:
+    another workload, or a library built from other sources than the ones the counters were collected on.
+    Hardware counters cannot be read from inside the process being timed."""
+    if not os.path.exists(PMC_FILE):
+        return None, "no committed PMC passes (profiles/r02_pmc.json)"
+    prof = json.load(open(PMC_FILE))
+    want = {"width": W, "height": H, "world": world, "small_scene": small_scene, "scene": scene, "project": project}
+    if prof.get("config") != want:
+        return None, f"the committed PMC passes are for {prof.get('config')}, this run is {want}"
+    if prof.get("source_hash") != source_hash():
+        return None, (f"the committed PMC passes were collected on sources {prof.get('source_hash')}, "
+                      f"the library here is built from {source_hash()}")
+    return prof["kernels"], None
 
 
 def cpu_baseline(rt, scene, cfg, frames, threads):
@@ -119,7 +139,7 @@ def main():
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-frames", type=int, default=2)
+    ap.add_argument("--cpu-frames", type=int, default=8)
     ap.add_argument("--small-scene", action="store_true", help="8.7k-triangle dragon instead of the 78k stand-in")
     ap.add_argument("--scene", choices=("80k", "instanced", "unique"), default="80k",
                     help="instanced: 16x8 instances of the 78k dragon (10 M triangles through one shared mesh BVH) lit by "
@@ -244,6 +264,16 @@ def main():
     iprof = ctx.profile()
     ctx.enable_stats(0)
 
+    # N > 1: where each rank's frame goes - dispatch-stream time before / beside / after the halo exchange, the exchange
+    # and the gather on the transfer stream, and the part of the exchange the dispatch stream had to wait for.
+    per_rank = None
+    if world > 1 and hasattr(runner, "timed_frames"):
+        import torch.distributed as dist
+        mine = {"rank": rank, "rows": [int(runner.bounds[rank]), int(runner.bounds[rank + 1])],
+                "ms": {k: round(v, 4) for k, v in runner.timed_frames(8).items()}}
+        per_rank = [None] * world
+        dist.all_gather_object(per_rank, mine)
+
     if rank == 0:
         proj = "BVH_RIS_DL" if ris else "BVH_ReSTIR_DL"
         band_px = runner.band_pixels()
@@ -256,17 +286,43 @@ def main():
                 b = algorithmic_bytes(name, c, band_px)
                 entry["counters_per_launch"] = {k: round(v) for k, v in c.items() if v}
                 entry["algorithmic_MB_per_launch"] = b / 1e6
-                entry["achieved_GBs"] = b / 1e9 / (ms / 1e3) if ms > 0 else None
+                entry["achieved_GBs"] = b / 1e9 / (ms / 1e3) if ms > 0 else None   # algorithmic bytes over time
             kernels[name] = entry
+        # What crossed the HBM interface, per kernel, from the committed PMC passes of this same command and build.
+        pmc, pmc_reason = pmc_profile(W, H, world, args.small_scene, args.scene, args.project)
+        for name, entry in kernels.items():
+            k = (pmc or {}).get(name)
+            if k and entry["avg_ms"] > 0:
+                entry["hbm_MB_per_launch"] = k["hbm_bytes_per_launch"] / 1e6
+                entry["hbm_GBs"] = k["hbm_bytes_per_launch"] / 1e9 / (entry["avg_ms"] / 1e3)
+                entry["hbm_frac"] = entry["hbm_GBs"] / HBM_PEAK_GBS
+                for key in ("valu_busy_frac", "wave_wait_frac", "ta_busy_frac", "td_busy_frac", "l1_accesses_per_cu_clk", "l1_hit_frac"):
+                    if key in k:
+                        entry[key] = round(k[key], 3)
+        # The roofline of the dominant kernel is drawn against the HBM roof with the bytes that really crossed it
+        # (`traffic`, PMC), so `frac` is a fraction of the peak.  The algorithmic bytes - what the REFERENCE's access
+        # pattern moves for the same work (32 bytes per node popped and per child box, 28 + 60 per triangle ...) - are
+        # reported beside it: the traversal kernels re-read a 15 MB scene through L1/L2, so they are a multiple of the
+        # traffic and say how much re-reading the caches absorb, not how busy the DRAM is.
         roofline = None
-        if kernels.get(dominant, {}).get("achieved_GBs"):
+        if dominant in kernels:
             d = kernels[dominant]
-            roofline = {"bound": "hbm", "kernel": dominant, "achieved": d["achieved_GBs"], "peak": HBM_PEAK_GBS,
-                        "unit": "GB/s", "frac": d["achieved_GBs"] / HBM_PEAK_GBS,
-                        "traffic": None if ris else pmc_traffic(dominant, W, H, world, args.small_scene, args.scene),
-                        "avg_launch_ms": d["avg_ms"], "algorithmic_MB_per_launch": d["algorithmic_MB_per_launch"]}
-            if roofline["traffic"]:   # what actually crossed the HBM interface, as a rate
-                roofline["hbm_GBs_from_pmc"] = roofline["traffic"] / 1e9 / (d["avg_ms"] / 1e3)
+            traffic = (pmc or {}).get(dominant, {}).get("hbm_bytes_per_launch")
+            achieved = traffic / 1e9 / (d["avg_ms"] / 1e3) if traffic and d["avg_ms"] > 0 else None
+            roofline = {"bound": "hbm", "kernel": dominant, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": achieved / HBM_PEAK_GBS if achieved else None, "traffic": traffic,
+                        "avg_launch_ms": d["avg_ms"]}
+            if traffic is None:
+                roofline["traffic_reason"] = pmc_reason
+            if d.get("algorithmic_MB_per_launch"):
+                roofline["algorithmic"] = {"MB_per_launch": d["algorithmic_MB_per_launch"], "GBs": d["achieved_GBs"],
+                                           "times_the_hbm_traffic": d["algorithmic_MB_per_launch"] * 1e6 / traffic if traffic else None,
+                                           "served_by": "L1/L2: the scene (15 MB with the wide nodes and baked triangles) stays cache resident"}
+            if "valu_busy_frac" in d:   # no unit is saturated: the kernel is bound by its chains of dependent steps
+                roofline["limiter"] = {"kind": "latency of dependent traversal steps", "valu_busy_frac": d["valu_busy_frac"],
+                                       "wave_wait_frac": d["wave_wait_frac"], "ta_busy_frac": d["ta_busy_frac"],
+                                       "td_busy_frac": d["td_busy_frac"], "l1_accesses_per_cu_clk": d["l1_accesses_per_cu_clk"],
+                                       "l1_hit_frac": d["l1_hit_frac"]}
         # this rank's rays over the time of the kernels that cast them (InitialTrace + TraceRays) only
         trav_ms = sum(v["avg_ms"] * v["launches_per_frame"] for k, v in kernels.items()
                       if k in ("primary", "candidates", "trace_rays", "ris_primary", "ris_trace_rays"))
@@ -292,9 +348,18 @@ def main():
             "kernel_timing": f"HIP events on the library's stream: '{dominant}' around every launch of the timed region, "
                              f"the other kernels in {n_breakdown} untimed frames after it",
         }
+        if per_rank:
+            out["per_rank_frame_ms"] = per_rank
+            out["per_rank_note"] = ("8 further frames, each waited for; 'frame' is dispatch-stream time, 'halo_exchange' and "
+                                    "'gather' run on the transfer stream, 'halo_exposed' is the wait the exchange cost the frame")
         if world == 1 and not args.no_cpu_baseline:
-            threads = min(16, os.cpu_count() or 1)
+            # all the host cores this process may use: its CPU affinity, or the share the launcher announces through
+            # OMP_NUM_THREADS (the GPU boxes give a one-GPU job 16 of the machine's cores and say so there)
+            threads = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+            if os.environ.get("OMP_NUM_THREADS", "").isdigit():
+                threads = max(1, min(threads, int(os.environ["OMP_NUM_THREADS"])))
             out["cpu_baseline"] = cpu_baseline(rt, scene, cfg, args.cpu_frames, threads)
+            out["cpu_baseline"]["host_cpus_visible"] = os.cpu_count()
         print(json.dumps(out))
     runner.close()
 

@@ -471,7 +471,6 @@ struct rth_mg_s {
     std::vector<int> bounds;
     Rccl::comm_t comm = nullptr;
     bool timing = false;
-    bool gatherPending = false;  // a gather is in flight on the transfer stream (TraceRays must wait for it)
     double sums[RTH_MG_TIMES] = {};
     int timedFrames = 0;
     std::string err;
@@ -817,7 +816,6 @@ int rth_mg_render_frames(rth_mg g, int n) {
                 mgMark(g, 1, MK_GATHER0);
                 mgRun(g, plan);
                 mgMark(g, 1, MK_GATHER1);
-                g->gatherPending = true;
             }
             if (g->timing) {  // reading the stamps waits for the frame: timing mode gives up the overlap between frames
                 g->sums[RTH_MG_T_FRAME] += mgElapsed(g, MK_FRAME, MK_END);

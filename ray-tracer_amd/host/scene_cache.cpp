@@ -5,7 +5,14 @@
 //
 // Read: what ObjectHelper.ConstructScene returns in LoadExistingFile mode (ObjectHelper.cs:672-677,493-517) —
 // loadedBVs, loadedVertices, renderTriangles, sceneObjectDatas, lightObjects plus the keyed integers and floats —
-// and loadedComponentDatas.  Written: the same files, plus the empty renderBVs.json the reference's own writer leaves.
+// and loadedComponentDatas.  Written: all twelve files of SaveMultiArrayContainerToJsonFiles (FileLoader.cs:26-44), so that
+// LoadMultiArrayContainerFromJsonFiles (FileLoader.cs:63-91) finds every array it wraps: the ones above, the empty
+// renderBVs.json the reference's own writer leaves, and the three that only the reference's scene construction reads
+// back (ObjectHelper.cs:499-504,627-631) - loadedTriangles (Triangle.cs:7-13: indices, parentIndex, min, max, area),
+// loadedMeshesLookup (scene object -> mesh) and loadedMeshes (MeshData.cs:6-11).  A mesh is a distinct bvStartIndex;
+// its triangles are the root volume's component range, its local box the root volume's.  meshKey is Unity's digest of
+// the imported Mesh asset (Resources.cs:90-135), which a scene built here does not have: the keys written are
+// "rth-mesh-<n>", which match no asset, so Unity re-imports a mesh it is asked to add again instead of mistaking it.
 // Files may carry a `<prefix>_` in front of the key, as the copy committed with the reference does (`80kScene_`).
 #include "rth_api.h"
 #include "scene_internal.h"
@@ -236,6 +243,56 @@ int rth_scene_save_json(rth_scene s, const char* folder) {
         for (int64_t i = 0; i < d.nComponentDatas; i++) {
             w.sep();
             fprintf(w.fp, "        {\n%s\"x\": %d,\n%s\"y\": %d\n        }", I3, d.ComponentDatas[i].x, I3, d.ComponentDatas[i].y);
+        }
+    });
+    // meshes: the distinct mesh BVH roots, in order of first use
+    std::vector<int> meshRoot, lookup((size_t)d.nSceneObjects, 0);
+    for (int64_t i = 0; i < d.nSceneObjects; i++) {
+        const int root = d.SceneObjects[i].bvStartIndex;
+        size_t m = 0;
+        while (m < meshRoot.size() && meshRoot[m] != root) m++;
+        if (m == meshRoot.size()) meshRoot.push_back(root);
+        lookup[(size_t)i] = (int)m;
+    }
+    auto triFields = [&](const rt_triangle& t, const std::string& ind) {
+        rt_float3 lo = d.Vertices[t.vertex0Index].pos, hi = lo;
+        for (int vi : {t.vertex1Index, t.vertex2Index}) {
+            const rt_float3 p = d.Vertices[vi].pos;
+            lo = {std::fmin(lo.x, p.x), std::fmin(lo.y, p.y), std::fmin(lo.z, p.z)};
+            hi = {std::fmax(hi.x, p.x), std::fmax(hi.y, p.y), std::fmax(hi.z, p.z)};
+        }
+        const char* in = ind.c_str();
+        return ind + "\"vertex0Index\": " + std::to_string(t.vertex0Index) + ",\n" + ind + "\"vertex1Index\": " + std::to_string(t.vertex1Index) + ",\n" +
+               ind + "\"vertex2Index\": " + std::to_string(t.vertex2Index) + ",\n" + ind + "\"parentIndex\": 0,\n" +   // never assigned by the reference
+               ind + "\"min\": " + vec3(lo, in) + ",\n" + ind + "\"max\": " + vec3(hi, in) + ",\n" + ind + "\"area\": " + num(t.area) + "\n";
+    };
+    bool indexed = true;   // every triangle's vertices exist, every mesh root has its component entry
+    for (int64_t i = 0; i < d.nTriangles && indexed; i++)
+        for (int vi : {d.Triangles[i].vertex0Index, d.Triangles[i].vertex1Index, d.Triangles[i].vertex2Index}) indexed &= vi >= 0 && vi < d.nVertices;
+    for (int root : meshRoot) {
+        indexed &= root >= 0 && root < d.nComponentDatas && root < d.nBVs;
+        if (indexed) indexed &= d.ComponentDatas[root].x >= 0 && d.ComponentDatas[root].y >= 0 && (int64_t)d.ComponentDatas[root].x + d.ComponentDatas[root].y <= d.nTriangles;
+    }
+    if (!indexed) return -1;
+    ok &= writeKey(dir, "loadedTriangles", [&](Writer& w) {
+        for (int64_t i = 0; i < d.nTriangles; i++) {
+            w.sep();
+            fprintf(w.fp, "        {\n%s        }", triFields(d.Triangles[i], I3).c_str());
+        }
+    });
+    ok &= writeKey(dir, "loadedMeshesLookup", [&](Writer& w) {
+        for (int m : lookup) { w.sep(); fprintf(w.fp, "        %d", m); }
+    });
+    ok &= writeKey(dir, "loadedMeshes", [&](Writer& w) {
+        const std::string I5 = std::string(I3) + "        ";
+        for (size_t m = 0; m < meshRoot.size(); m++) {
+            const int root = meshRoot[m], start = d.ComponentDatas[root].x, count = d.ComponentDatas[root].y;
+            w.sep();
+            fprintf(w.fp, "        {\n%s\"triangles\": [", I3);
+            for (int t = 0; t < count; t++)
+                fprintf(w.fp, "%s\n%s    {\n%s%s    }", t ? "," : "", I3, triFields(d.Triangles[start + t], I5).c_str(), I3);
+            fprintf(w.fp, "%s],\n%s\"localMin\": %s,\n%s\"localMax\": %s,\n%s\"componentStartIndex\": %d,\n%s\"bvStartIndex\": %d,\n%s\"meshKey\": \"rth-mesh-%zu\"\n        }",
+                    count ? (std::string("\n") + I3).c_str() : "", I3, vec3(d.BVs[root].min, I3).c_str(), I3, vec3(d.BVs[root].max, I3).c_str(), I3, start, I3, root, I3, m);
         }
     });
     ok &= writeKey(dir, "integers", [&](Writer& w) {

@@ -76,6 +76,48 @@ def test_written_text_matches_the_reference_files(scene_small, tmp_path):
     assert [strip(l) for l in mine] == [strip(l) for l in ref]
 
 
+def test_every_file_the_reference_loader_wraps_is_written(scene_small, tmp_path):
+    """LoadMultiArrayContainerFromJsonFiles (FileLoader.cs:73-87) reads twelve arrays and wraps loadedMeshes in a List:
+    a missing file is a null array and the List constructor throws.  The three arrays only the reference's own scene
+    construction uses are checked field by field against Triangle.cs:7-13 and MeshData.cs:6-11."""
+    scene_small.save_json(str(tmp_path))
+    keys = ("loadedTriangles", "sceneObjectDatas", "lightObjects", "loadedMeshesLookup", "loadedComponentDatas", "loadedMeshes",
+            "loadedBVs", "loadedVertices", "integers", "floats", "renderBVs", "renderTriangles")
+    assert sorted(os.listdir(tmp_path)) == sorted(f"{k}.json" for k in keys)
+    data = {k: json.load(open(tmp_path / f"{k}.json"))["array"] for k in keys}
+    a = scene_small.arrays()
+    tris, verts = data["loadedTriangles"], a["Vertices"]["pos"]
+    assert len(tris) == len(a["Triangles"]) == len(data["renderTriangles"])
+    for i in (0, 1, len(tris) // 2, len(tris) - 1):
+        t = tris[i]
+        assert list(t) == ["vertex0Index", "vertex1Index", "vertex2Index", "parentIndex", "min", "max", "area"]
+        idx = [t["vertex0Index"], t["vertex1Index"], t["vertex2Index"]]
+        assert idx == [int(v) for v in a["Triangles"][i]["v"]] and t["parentIndex"] == 0
+        assert np.array_equal(np.array([t["min"][c] for c in "xyz"], np.float32), verts[idx].min(axis=0))
+        assert np.array_equal(np.array([t["max"][c] for c in "xyz"], np.float32), verts[idx].max(axis=0))
+        assert np.float32(t["area"]) == a["Triangles"][i]["area"]
+    # one mesh per distinct mesh BVH, in order of first use; every scene object points at its own
+    lookup, meshes = data["loadedMeshesLookup"], data["loadedMeshes"]
+    assert len(lookup) == len(a["SceneObjects"]) and sorted(set(lookup)) == list(range(len(meshes)))
+    total = 0
+    for o, m in zip(a["SceneObjects"], lookup):
+        mesh = meshes[m]
+        assert list(mesh) == ["triangles", "localMin", "localMax", "componentStartIndex", "bvStartIndex", "meshKey"]
+        root = int(o["bvStartIndex"])
+        assert mesh["bvStartIndex"] == root
+        start, count = (int(v) for v in a["ComponentDatas"][root])
+        assert mesh["componentStartIndex"] == start and len(mesh["triangles"]) == count
+        assert mesh["triangles"][0] == tris[start] and mesh["triangles"][-1] == tris[start + count - 1]
+        assert np.array_equal(np.array([mesh["localMin"][c] for c in "xyz"], np.float32), a["BVs"][root]["min"])
+        assert np.array_equal(np.array([mesh["localMax"][c] for c in "xyz"], np.float32), a["BVs"][root]["max"])
+        assert isinstance(mesh["meshKey"], str) and mesh["meshKey"]
+    for mesh in meshes:
+        total += len(mesh["triangles"])
+    assert total == len(tris)
+    # the layout of the text is JsonUtility's pretty print: the committed lookup file of the reference, byte for byte
+    assert open(tmp_path / "loadedMeshesLookup.json").read() == '{\n    "array": [\n        0,\n        1\n    ]\n}'
+
+
 def test_errors_name_the_file(scene_small, tmp_path):
     scene_small.save_json(str(tmp_path))
     os.remove(tmp_path / "loadedVertices.json")
