@@ -332,6 +332,7 @@ struct TravState {
     int sp, objBase, objCur, objEnd, curObj, localTri;
     float localU, localV;
     uint32_t e;              // entry to visit next, or ENTRY_NONE
+    uint32_t top;            // newest of the `sp` stacked entries (see travPush)
 };
 
 template <bool INSTR>
@@ -342,18 +343,32 @@ DEV void travBegin(const KParams& P, TravState& s, Trav& t, v3 wpos, v3 wdir, v3
     s.sp = 0; s.objBase = -1; s.objCur = 0; s.objEnd = 0; s.curObj = -1; s.localTri = -1;
     s.localU = 0; s.localV = 0;
     s.e = P.sceneRootEntry;
+    s.top = ENTRY_NONE;
     t.tri = -1; t.obj = -1; t.steps = 0; t.u = 0; t.v = 0; t.triChecks = 0; t.bvChecks = 0;
     if (INSTR) { t.hash = 2166136261u; t.pops = 1; t.objVisits = 0; t.triIters = 0; t.iters = 0; }
 }
 template <bool INSTR>
 DEV void travResetWaveCounts(Trav& t) { if (INSTR) t.wInt = t.wIntLanes = t.wLeaf = t.wLeafLanes = t.wSvc = 0; }
+// The stack keeps its newest entry in a register: a pop hands that register over at once and refills it from LDS behind
+// the fetch of the popped node, instead of putting an LDS read in front of it.  Entry j (counted from the oldest) moves
+// to slot j + 1 when the next one is pushed; slot 0 only ever receives the unused register of an empty stack.  The stack
+// holds the deepest path of the validated scene plus that slot: there is no overflow to guard against.
+DEV void travPush(TravState& s, uint32_t* stk, uint32_t entry) {
+    stk[s.sp * 64] = s.top;
+    s.top = entry;
+    s.sp++;
+}
+DEV void travTake(TravState& s, const uint32_t* stk) {  // s.sp > 0
+    s.e = s.top;
+    --s.sp;
+    s.top = stk[s.sp * 64];
+}
 // Next entry of the level being traversed, or ENTRY_NONE when that level's part of the stack is used up.
 template <bool INSTR>
 DEV void travPop(const KParams& P, TravState& s, Trav& t, const uint32_t* stk) {
     const int floor = s.objBase >= 0 ? s.objBase : 0;
     if (s.sp > floor) {
-        --s.sp;
-        s.e = s.sp < P.stackDepth ? stk[s.sp * 64] : ENTRY_LEAF;  // overflowed pushes come back as empty leaves
+        travTake(s, stk);
         if (INSTR) t.pops++;
     } else {
         s.e = ENTRY_NONE;
@@ -383,8 +398,7 @@ DEV bool travService(const KParams& P, TravState& s, Trav& t, const uint32_t* st
         return true;
     }
     if (s.sp == 0) { t.dst = s.worldBest; return false; }
-    --s.sp;
-    s.e = s.sp < P.stackDepth ? stk[s.sp * 64] : ENTRY_LEAF;
+    travTake(s, stk);
     if (INSTR) t.pops++;
     return true;
 }
@@ -393,7 +407,9 @@ template <bool INSTR, bool RIS>
 DEV void travInternal(const KParams& P, TravState& s, Trav& t, uint32_t* stk) {
     const uint32_t e = s.e;
     if (INSTR) { t.iters++; t.hash = (t.hash ^ (0x80000000u | e)) * 16777619u; }
-    const float4* rec = P.wide + (int64_t)e * 4;
+    // 32-bit byte offset from a uniform base (one shift instead of 64-bit address arithmetic; the scene check keeps
+    // the node and triangle counts below 2^26)
+    const float4* rec = (const float4*)((const char*)P.wide + (e << 6));
     const float4 q0 = rec[0], q1 = rec[1], q2 = rec[2];
     const float2 q3 = *(const float2*)(rec + 3);  // the two child entries
     float dstA, dstB;
@@ -410,7 +426,7 @@ DEV void travInternal(const KParams& P, TravState& s, Trav& t, uint32_t* stk) {
     const bool nearHit = (aFirst ? dstA : dstB) < s.best, farHit = (aFirst ? dstB : dstA) < s.best;
     // Written flat (one predicated push, one predicated pop) instead of as nested branches: fewer exec-mask
     // regions per step.  A far child can pass while the near one fails only when a distance is NaN.
-    if (nearHit && farHit) { if (s.sp < P.stackDepth) stk[s.sp * 64] = eFar; s.sp++; }
+    if (nearHit && farHit) travPush(s, stk, eFar);
     if (nearHit || farHit) {
         s.e = nearHit ? eNear : eFar;
         if (INSTR) t.pops++;
@@ -442,12 +458,14 @@ DEV void travLeaf(const KParams& P, TravState& s, Trav& t, const uint32_t* stk) 
         return;
     }
     for (int triIndex = start; triIndex < start + count; triIndex++) {
-        const float4* rec = P.btri + (int64_t)triIndex * 4;
+        const float4* rec = (const float4*)((const char*)P.btri + ((uint32_t)triIndex << 6));
         if (INSTR) t.triIters++;
         bool facing = true;
+        // the whole record in one round trip: fetching the vertices only for triangles that pass the back-face
+        // pre-cull saves requests, but puts two memory latencies into every iteration of a dependent loop
+        const float4 q0 = rec[0], q1 = rec[1], q2 = rec[2];
         if (!RIS) { const float4 q3 = rec[3]; facing = dot(V3(q3.x, q3.y, q3.z), s.rdir) <= 0; }
         if (facing) {
-            const float4 q0 = rec[0], q1 = rec[1], q2 = rec[2];
             // RayTriangleIntersect, RS:119-146
             v3 edgeAB = V3(q1.x, q1.y, q1.z), edgeAC = V3(q2.x, q2.y, q2.z);
             v3 normalVector = V3(q0.w, q1.w, q2.w);

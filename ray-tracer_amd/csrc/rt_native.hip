@@ -300,7 +300,9 @@ int prepareScene(rt_shader sh, int kernel, KParams& P, bool ris = false) {
         HIP_TRY(ctx, hipMemcpy(bvs.data(), bBVs->dev, bvs.size() * sizeof(rt_bv), hipMemcpyDeviceToHost));
         HIP_TRY(ctx, hipMemcpy(objs.data(), bObjs->dev, objs.size() * sizeof(rt_scene_object), hipMemcpyDeviceToHost));
         if (!ris) HIP_TRY(ctx, hipMemcpy(tris.data(), bTris->dev, tris.size() * sizeof(rt_triangle), hipMemcpyDeviceToHost));
-        if (bvs.size() >= (size_t)ENTRY_INDEX_MASK) return fail(ctx, RT_ERR_BAD_SCENE, "too many BVH nodes");
+        // the kernels address the 64-byte node and triangle records with 32-bit byte offsets
+        if (bvs.size() >= ((size_t)1 << 26)) return fail(ctx, RT_ERR_LIMIT, "too many BVH nodes: %zu, the limit is 2^26 - 1", bvs.size());
+        if ((uint64_t)bTris->count >= ((uint64_t)1 << 26)) return fail(ctx, RT_ERR_LIMIT, "too many triangles: %lld, the limit is 2^26 - 1", (long long)bTris->count);
         if (sceneStart >= bvs.size()) return fail(ctx, RT_ERR_BAD_SCENE, "SceneBVHStartIndex %u is outside the BVs buffer", sceneStart);
         for (const auto& t : tris)
             if (t.vertex0Index < 0 || t.vertex1Index < 0 || t.vertex2Index < 0 || t.vertex0Index >= bVerts->count ||
@@ -320,7 +322,7 @@ int prepareScene(rt_shader sh, int kernel, KParams& P, bool ris = false) {
             meshDepth[o.bvStartIndex] = d;
             if (d > maxMeshDepth) maxMeshDepth = d;
         }
-        pr.stackDepth = sceneDepth + maxMeshDepth + 2;
+        pr.stackDepth = sceneDepth + maxMeshDepth + 3;   // the deepest path, one slot for the register-held top, slack
         // the per-lane stack lives in LDS: 4 waves x 64 lanes x 4 bytes per entry, within the 64 KiB a workgroup may ask for
         if ((size_t)WAVES_PER_BLOCK * pr.stackDepth * 64 * 4 > 65536)
             return fail(ctx, RT_ERR_LIMIT, "BVH too deep: scene BVH of %d levels + mesh BVH of %d levels need a traversal stack of %d entries, the limit is %d",
