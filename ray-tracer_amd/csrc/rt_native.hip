@@ -322,7 +322,7 @@ int prepareScene(rt_shader sh, int kernel, KParams& P, bool ris = false) {
             meshDepth[o.bvStartIndex] = d;
             if (d > maxMeshDepth) maxMeshDepth = d;
         }
-        pr.stackDepth = sceneDepth + maxMeshDepth + 3;   // the deepest path, one slot for the register-held top, slack
+        pr.stackDepth = sceneDepth + maxMeshDepth;   // entries stacked on the deepest path (one per internal level) + 2
         // the per-lane stack lives in LDS: 4 waves x 64 lanes x 4 bytes per entry, within the 64 KiB a workgroup may ask for
         if ((size_t)WAVES_PER_BLOCK * pr.stackDepth * 64 * 4 > 65536)
             return fail(ctx, RT_ERR_LIMIT, "BVH too deep: scene BVH of %d levels + mesh BVH of %d levels need a traversal stack of %d entries, the limit is %d",
