@@ -86,7 +86,7 @@ def source_hash():
 PMC_FILE = os.path.join(ROOT, "profiles", "r02_pmc.json")
 
 
-def pmc_profile(W, H, world, small_scene, scene, project):
+def pmc_profile(W, H, world, small_scene, scene, project, extra=None):
     """(per-kernel PMC figures, None) from the committed rocprofv3 --pmc passes over this same command
     (tools/collect_profiles.sh -> tools/make_pmc_profile.py), or (None, reason) when they do not describe this run:
     another workload, or a library built from other sources than the ones the counters were collected on.
@@ -95,6 +95,8 @@ def pmc_profile(W, H, world, small_scene, scene, project):
         return None, "no committed PMC passes (profiles/r02_pmc.json)"
     prof = json.load(open(PMC_FILE))
     want = {"width": W, "height": H, "world": world, "small_scene": small_scene, "scene": scene, "project": project}
+    if extra:
+        want.update(extra)
     if prof.get("config") != want:
         return None, f"the committed PMC passes are for {prof.get('config')}, this run is {want}"
     if prof.get("source_hash") != source_hash():
@@ -151,6 +153,8 @@ def main():
     ap.add_argument("--project", choices=("restir", "ris"), default="restir",
                     help="ris: the RIS project's frame (GenerateCandidates with 32 candidates per pixel, TraceRays "
                          "drawing 32 of them, AccumulateFrames) instead of the ReSTIR sequence")
+    ap.add_argument("--tri-reservoir-tests", type=int, default=None,
+                    help="ReSTIR project: TriReservoirTestsNum (default 5; the 256x256 CPU-runnable configuration uses 32)")
     ap.add_argument("--exchange", choices=("rccl", "torch"), default="rccl",
                     help="N > 1: halo exchange from the C++ frame loop with RCCL calls (default), or from Python with "
                          "torch.distributed's NCCL backend")
@@ -180,6 +184,8 @@ def main():
         args.exchange = "rccl"        # its banded loop exists in the native driver only
     else:
         cfg = rt.default_config()
+        if args.tri_reservoir_tests is not None:
+            cfg.TriReservoirTestsNum = args.tri_reservoir_tests
     cfg.Resolution[0], cfg.Resolution[1] = args.width, args.height
     W, H = args.width, args.height
 
@@ -289,7 +295,8 @@ def main():
                 entry["achieved_GBs"] = b / 1e9 / (ms / 1e3) if ms > 0 else None   # algorithmic bytes over time
             kernels[name] = entry
         # What crossed the HBM interface, per kernel, from the committed PMC passes of this same command and build.
-        pmc, pmc_reason = pmc_profile(W, H, world, args.small_scene, args.scene, args.project)
+        pmc, pmc_reason = pmc_profile(W, H, world, args.small_scene, args.scene, args.project,
+                                      {"tri_reservoir_tests": args.tri_reservoir_tests} if args.tri_reservoir_tests is not None else None)
         for name, entry in kernels.items():
             k = (pmc or {}).get(name)
             if k and entry["avg_ms"] > 0:
@@ -337,7 +344,8 @@ def main():
                                     f"{proj} {args.scene} 80kScene* (128 dragon "
                                     f"{'instances' if args.scene == 'instanced' else 'meshes, each distinct'} + 10 emissive discs{' (fans)' if args.emissive_fans else ''})") +
                                    (f" {W}x{H}, RIS project: {RIS_TOT} candidates per pixel, {RIS_TESTS} drawn" if ris else
-                                    f" {W}x{H}, temporal + 3 spatial reuse passes, VIS_REUSE+BRDF"),
+                                    f" {W}x{H}, temporal + 3 spatial reuse passes, VIS_REUSE+BRDF" +
+                                    (f", TriReservoirTestsNum {args.tri_reservoir_tests}" if args.tri_reservoir_tests is not None else "")),
                        "instanced_triangles": int(sum(scene.arrays()["ComponentDatas"][o["bvStartIndex"]][1]
                                                       for o in scene.arrays()["SceneObjects"])),
                        "resolution": [W, H], "triangles": int(len(scene.arrays()['Triangles'])),
