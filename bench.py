@@ -226,10 +226,15 @@ def main():
     # Warm-up, with every launch bracketed by events: tells which kernel dominates the frame.
     ctx.profile_reset()
     ctx.profile_enable(True)
-    for _ in range(args.warmup):
+    for i in range(args.warmup):
+        if i == args.warmup // 2 and i > 0:   # the first frames run before the regions are ranked and without history
+            runner.sync()
+            ctx.profile_reset()
         runner.render_frame()
     runner.sync()
     wprof = ctx.profile()
+    if os.environ.get("RT_BENCH_DEBUG"):
+        print({k: round(v["ms"] / max(1, v["launches"]) * 1e3, 1) for k, v in wprof.items()}, file=sys.stderr)
     dominant = max(wprof, key=lambda k: wprof[k]["ms"]) if wprof else ("ris_trace_rays" if ris else "trace_rays")
     # Timed region: the kernels count their rays, and only the dominant kernel's launches carry events (a pair of
     # events costs a few microseconds of stream time; around all ten launches of a frame they cost 6 % of it).
