@@ -324,23 +324,30 @@ DEV float RayBVIntersectDiv(v3 pos, v3 dir, v3 bmin, v3 bmax) {
 // divides by the direction and the leaf loop has no back-face pre-cull.
 constexpr uint32_t ENTRY_NONE = 0xffffffffu;  // no entry held (never a valid entry: an inline leaf with count 31 at
                                               // start 2^26-1 is rejected when the scene is validated)
+constexpr uint32_t ENTRY_DEAD = 0xfffffffeu;  // the lane's ray has ended (likewise never a valid entry: count 31 at start 2^26-2)
 constexpr uint32_t LEAF_BITS = ENTRY_LEAF | ENTRY_LEAF_INDIRECT;
+// What a lane does next is read off its entry alone, one comparison each: internal entries are below the two leaf bits,
+// leaf entries from there up to the two reserved values.
+DEV bool entryIsInternal(uint32_t e) { return e < ENTRY_LEAF_INDIRECT; }
+DEV bool entryIsLeaf(uint32_t e) { return e - ENTRY_LEAF_INDIRECT < ENTRY_DEAD - ENTRY_LEAF_INDIRECT; }
 struct TravState {
     v3 wpos, wdir, winv;     // the ray in world space
     v3 rpos, rdir, rinv;     // ray of the level being traversed (world at scene level, object space inside an object)
     float best, worldBest;   // hitInfo.dst of the level being traversed / of the world level
-    int sp, objBase, objCur, objEnd, curObj, localTri;
+    uint32_t* sp;            // slot the next push writes (LDS address: a push or pop is one add, no index arithmetic)
+    uint32_t* floor;         // slot below which the entries belong to the enclosing level (scene level: the column's start)
+    int inObj, objCur, objEnd, curObj, localTri;   // inObj: inside a scene object's BVH
     float localU, localV;
     uint32_t e;              // entry to visit next, or ENTRY_NONE
     uint32_t top;            // newest of the `sp` stacked entries (see travPush)
 };
 
 template <bool INSTR>
-DEV void travBegin(const KParams& P, TravState& s, Trav& t, v3 wpos, v3 wdir, v3 winv) {
+DEV void travBegin(const KParams& P, TravState& s, Trav& t, v3 wpos, v3 wdir, v3 winv, uint32_t* stk) {
     s.wpos = wpos; s.wdir = wdir; s.winv = winv;
     s.rpos = wpos; s.rdir = wdir; s.rinv = winv;
     s.best = INF(); s.worldBest = INF();
-    s.sp = 0; s.objBase = -1; s.objCur = 0; s.objEnd = 0; s.curObj = -1; s.localTri = -1;
+    s.sp = stk; s.floor = stk; s.inObj = 0; s.objCur = 0; s.objEnd = 0; s.curObj = -1; s.localTri = -1;
     s.localU = 0; s.localV = 0;
     s.e = P.sceneRootEntry;
     s.top = ENTRY_NONE;
@@ -353,35 +360,36 @@ DEV void travResetWaveCounts(Trav& t) { if (INSTR) t.wInt = t.wIntLanes = t.wLea
 // the fetch of the popped node, instead of putting an LDS read in front of it.  Entry j (counted from the oldest) moves
 // to slot j + 1 when the next one is pushed; slot 0 only ever receives the unused register of an empty stack.  The stack
 // holds the deepest path of the validated scene plus that slot: there is no overflow to guard against.
-DEV void travPush(TravState& s, uint32_t* stk, uint32_t entry) {
-    stk[s.sp * 64] = s.top;
+DEV void travPush(TravState& s, uint32_t entry) {
+    *s.sp = s.top;
     s.top = entry;
-    s.sp++;
+    s.sp += 64;
 }
-DEV void travTake(TravState& s, const uint32_t* stk) {  // s.sp > 0
+DEV void travTake(TravState& s) {  // the stack is not empty
     s.e = s.top;
-    --s.sp;
-    s.top = stk[s.sp * 64];
+    s.sp -= 64;
+    __builtin_amdgcn_sched_barrier(0);  // (the refill below must not be scheduled above the hand-over: it would need a copy and a wait)
+    s.top = *s.sp;
 }
 // Next entry of the level being traversed, or ENTRY_NONE when that level's part of the stack is used up.
 template <bool INSTR>
-DEV void travPop(const KParams& P, TravState& s, Trav& t, const uint32_t* stk) {
-    const int floor = s.objBase >= 0 ? s.objBase : 0;
-    if (s.sp > floor) {
-        travTake(s, stk);
+DEV void travPop(const KParams& P, TravState& s, Trav& t) {
+    if (s.sp > s.floor) {
+        travTake(s);
         if (INSTR) t.pops++;
     } else {
         s.e = ENTRY_NONE;
     }
 }
-// Service step of one lane that holds ENTRY_NONE.  Returns false when the ray is finished.
+// Service step of one lane that holds ENTRY_NONE.  Leaves ENTRY_DEAD when the ray is finished.
 template <bool INSTR, bool RIS>
-DEV bool travService(const KParams& P, TravState& s, Trav& t, const uint32_t* stk) {
-    if (s.objBase >= 0) {  // the object's subtree is exhausted (RS:251-258)
+DEV void travService(const KParams& P, TravState& s, Trav& t, const uint32_t* stk) {
+    if (s.inObj) {  // the object's subtree is exhausted (RS:251-258)
         if (s.best < s.worldBest) { s.worldBest = s.best; t.tri = s.localTri; t.obj = s.curObj; t.u = s.localU; t.v = s.localV; }
         s.best = s.worldBest;
         s.rpos = s.wpos; s.rdir = s.wdir; s.rinv = s.winv;
-        s.objBase = -1;
+        s.inObj = 0;
+        s.floor = (uint32_t*)stk;
     }
     if (s.objCur < s.objEnd) {  // next scene object of the current scene-level leaf (RS:235-246)
         const float* m = P.objs[s.objCur].worldToLocalMatrix.m;
@@ -391,16 +399,16 @@ DEV bool travService(const KParams& P, TravState& s, Trav& t, const uint32_t* st
         s.best = INF();
         s.localTri = -1;
         s.curObj = s.objCur;
-        s.objBase = s.sp;
+        s.inObj = 1;
+        s.floor = s.sp;
         s.e = P.objRootEntry[s.objCur];
         s.objCur++;
         if (INSTR) { t.objVisits++; t.pops++; }
-        return true;
+        return;
     }
-    if (s.sp == 0) { t.dst = s.worldBest; return false; }
-    travTake(s, stk);
+    if (s.sp == stk) { t.dst = s.worldBest; s.e = ENTRY_DEAD; return; }
+    travTake(s);
     if (INSTR) t.pops++;
-    return true;
 }
 // One internal-node step of one lane (RS:195-214).
 template <bool INSTR, bool RIS>
@@ -426,13 +434,10 @@ DEV void travInternal(const KParams& P, TravState& s, Trav& t, uint32_t* stk) {
     const bool nearHit = (aFirst ? dstA : dstB) < s.best, farHit = (aFirst ? dstB : dstA) < s.best;
     // Written flat (one predicated push, one predicated pop) instead of as nested branches: fewer exec-mask
     // regions per step.  A far child can pass while the near one fails only when a distance is NaN.
-    if (nearHit && farHit) travPush(s, stk, eFar);
-    if (nearHit || farHit) {
-        s.e = nearHit ? eNear : eFar;
-        if (INSTR) t.pops++;
-    } else {
-        travPop<INSTR>(P, s, t, stk);
-    }
+    if (nearHit && farHit) travPush(s, eFar);
+    s.e = nearHit ? eNear : eFar;
+    if (nearHit || farHit) { if (INSTR) t.pops++; }
+    else travPop<INSTR>(P, s, t);
 }
 // Leaf step of one lane: a run of scene objects at scene level, a run of triangles inside an object (RS:179-193).
 template <bool INSTR, bool RIS>
@@ -451,7 +456,7 @@ DEV void travLeaf(const KParams& P, TravState& s, Trav& t, const uint32_t* stk) 
         count = b < 0 ? -b : b;
     }
     if (INSTR) t.iters++;
-    if (s.objBase < 0) {  // scene-level leaf: its objects are entered one by one by the service step
+    if (!s.inObj) {  // scene-level leaf: its objects are entered one by one by the service step
         s.objCur = start;
         s.objEnd = start + count;
         s.e = ENTRY_NONE;
@@ -483,41 +488,38 @@ DEV void travLeaf(const KParams& P, TravState& s, Trav& t, const uint32_t* stk) 
             if (didHit && dst < s.best) { s.best = dst; s.localU = u; s.localV = v; s.localTri = triIndex; }
         }
     }
-    travPop<INSTR>(P, s, t, stk);
+    travPop<INSTR>(P, s, t);
 }
-// One outer trip for the lanes with `alive` set: service, internal-node phase, leaf phase.  Clears `alive` (and sets
-// t.dst) for lanes whose ray ends.
+// One outer trip: service, internal-node phase, leaf phase.  A lane whose ray has ended holds ENTRY_DEAD (t.dst is set).
 template <bool INSTR, bool RIS>
-DEV void travTrip(const KParams& P, TravState& s, Trav& t, uint32_t* stk, bool& alive) {
-    if (INSTR && __builtin_amdgcn_ballot_w64(alive && s.e == ENTRY_NONE) != 0) t.wSvc++;
-    if (alive && s.e == ENTRY_NONE) alive = travService<INSTR, RIS>(P, s, t, stk);
+DEV void travTrip(const KParams& P, TravState& s, Trav& t, uint32_t* stk) {
+    if (INSTR && __builtin_amdgcn_ballot_w64(s.e == ENTRY_NONE) != 0) t.wSvc++;
+    if (s.e == ENTRY_NONE) travService<INSTR, RIS>(P, s, t, stk);
     // The phase is left once at least RT_LEAF_NUM / RT_LEAF_DEN of the lanes still at work wait for a leaf or for
     // service, i.e. once the lanes holding an internal entry are few enough (the live lanes do not change in it).
-    const int nAlive = __builtin_popcountll(__builtin_amdgcn_ballot_w64(alive));
-    bool isInt = alive && s.e != ENTRY_NONE && (s.e & LEAF_BITS) == 0;
-    int nInt = __builtin_popcountll(__builtin_amdgcn_ballot_w64(isInt));
+    const int nAlive = __builtin_popcountll(__builtin_amdgcn_ballot_w64(s.e != ENTRY_DEAD));
+    int nInt = __builtin_popcountll(__builtin_amdgcn_ballot_w64(entryIsInternal(s.e)));
     t.steps++;
-    while (nInt != 0) {
-        t.steps++;
-        if (INSTR) { t.wInt++; t.wIntLanes += (uint32_t)nInt; }
-        if (isInt) travInternal<INSTR, RIS>(P, s, t, stk);
-        isInt = alive && s.e != ENTRY_NONE && (s.e & LEAF_BITS) == 0;
-        nInt = __builtin_popcountll(__builtin_amdgcn_ballot_w64(isInt));
-        if (RT_LEAF_DEN * (nAlive - nInt) >= RT_LEAF_NUM * nAlive) break;
+    if (nInt != 0) {
+        do {
+            t.steps++;
+            if (INSTR) { t.wInt++; t.wIntLanes += (uint32_t)nInt; }
+            if (entryIsInternal(s.e)) travInternal<INSTR, RIS>(P, s, t, stk);
+            nInt = __builtin_popcountll(__builtin_amdgcn_ballot_w64(entryIsInternal(s.e)));
+        } while (RT_LEAF_DEN * nInt > (RT_LEAF_DEN - RT_LEAF_NUM) * nAlive);   // (false at the latest when no lane is left)
     }
     if (INSTR) {
-        const int nLeaf = __builtin_popcountll(__builtin_amdgcn_ballot_w64(alive && s.e != ENTRY_NONE && (s.e & LEAF_BITS) != 0));
+        const int nLeaf = __builtin_popcountll(__builtin_amdgcn_ballot_w64(entryIsLeaf(s.e)));
         if (nLeaf) { t.wLeaf++; t.wLeafLanes += (uint32_t)nLeaf; }
     }
-    if (alive && s.e != ENTRY_NONE && (s.e & LEAF_BITS) != 0) travLeaf<INSTR, RIS>(P, s, t, stk);
+    if (entryIsLeaf(s.e)) travLeaf<INSTR, RIS>(P, s, t, stk);
 }
 
 template <bool INSTR, bool RIS = false>
 DEV void traverse3(const KParams& P, const v3 wpos, const v3 wdir, const v3 winv, uint32_t* stk, Trav& t) {
     TravState s;
-    travBegin<INSTR>(P, s, t, wpos, wdir, winv);
-    bool alive = true;
-    while (__builtin_amdgcn_ballot_w64(alive) != 0) travTrip<INSTR, RIS>(P, s, t, stk, alive);
+    travBegin<INSTR>(P, s, t, wpos, wdir, winv, stk);
+    while (__builtin_amdgcn_ballot_w64(s.e != ENTRY_DEAD) != 0) travTrip<INSTR, RIS>(P, s, t, stk);
 }
 
 // Shading data of a traversal result, as TraverseSceneBVH leaves it in hitInfo (RS:248-258).
