@@ -42,3 +42,10 @@ print(f"wave-level steps in heavy waves: internal {wInt[h].sum():.0f} (active la
       f"leaf {wLeaf[h].sum():.0f} (active lanes/step {wLeafL[h].sum() / max(1, wLeaf[h].sum()):.1f}), service {wSvc[h].sum():.0f}")
 print(f"per heavy wave: internal steps {wInt[h].mean():.1f}, leaf steps {wLeaf[h].mean():.1f}, service {wSvc[h].mean():.1f}, max lane iters {mx[h].mean():.1f}")
 print(f"us per wave-level step (internal+leaf): {(dur[h].sum() / (wInt[h].sum() + wLeaf[h].sum())):.3f}")
+# the waves that end last: what their time is made of
+end = (a["t1"] - a["t0"].min()) / 100.0
+for i in np.argsort(-end)[:12]:
+    print(f"ends {end[i]:6.1f} us  starts {t0[i]:6.1f}  lives {dur[i]:6.1f}  internal {wInt[i]:4.0f} @ {wIntL[i] / max(1, wInt[i]):4.1f} lanes  leaf {wLeaf[i]:3.0f} @ {wLeafL[i] / max(1, wLeaf[i]):4.1f}  service {wSvc[i]:3.0f}  "
+          f"us/step {dur[i] / max(1, wInt[i] + wLeaf[i] + wSvc[i]):.3f}  longest lane {mx[i]:.0f} iterations")
+steps = wInt + wLeaf + wSvc
+print("steps of a wave: p50 %.0f p90 %.0f p99 %.0f max %.0f" % (*np.percentile(steps[h], [50, 90, 99]), steps.max()))
