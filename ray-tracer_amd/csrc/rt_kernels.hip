@@ -1053,7 +1053,11 @@ DEV v3 SampleEnvironmentMap(const KParams& P, v3 dir) {  // RS:102-117
 
 // Four waves per SIMD: the bounce loop keeps some 110 values live around the traversal, and held to the 96 registers of
 // five waves it spills 49 of them into the loop (256 us against 239 us at 1080p).
-template <bool INSTR>
+// XFER: the launch also makes TransferToOriginal's copy (RS:575-582) for its pixel - CandidatesB to Candidates where the
+// depth buffer holds a hit - and takes the reservoir it shades with from that copy.  ACC: it also makes
+// AccumulateFrames' running average (PostProcessor.compute:10-19) of the colour it stores.  Both are what the separate
+// kernels would do to this pixel, in the same order.
+template <bool INSTR, bool XFER = false, bool ACC = false>
 __global__ __launch_bounds__(256, 4) void k_trace_rays(const KParams P) {
     extern __shared__ uint32_t lds[];
     const Pixel px = pixelOfThread(P);
@@ -1073,7 +1077,15 @@ __global__ __launch_bounds__(256, 4) void k_trace_rays(const KParams P) {
         HitInfo hitInfo;
         hitInfo.dst = P.hit.p0[i].w;
         Reservoir cr = emptyReservoir();
-        if (hitInfo.dst != INF()) { hitInfo = loadHit(P, i); cr = loadReservoir(P.cand, pixelIndex); }
+        if (XFER) {
+            Reservoir moved = emptyReservoir();
+            const bool move = P.depth.r[i] != INF();   // k_transfer's condition; both buffers hold a record per pixel (checked at dispatch)
+            if (move) { moved = loadReservoir(P.candB, i); storeReservoir(P.cand, i, moved); }
+            if (hitInfo.dst != INF()) {
+                hitInfo = loadHit(P, i);
+                cr = move ? moved : loadReservoir(P.cand, pixelIndex);
+            }
+        } else if (hitInfo.dst != INF()) { hitInfo = loadHit(P, i); cr = loadReservoir(P.cand, pixelIndex); }
         if (hitInfo.dst == INF()) {  // a pixel whose primary ray missed needs only the incoming direction
             const float4 c = P.hit.p2[i];
             v3 col = SampleEnvironmentMap(P, V3(c.x, c.y, c.z));
@@ -1147,7 +1159,21 @@ __global__ __launch_bounds__(256, 4) void k_trace_rays(const KParams P) {
             if (INSTR && P.records && rays) P.records[i * RECORD_DWORDS + 7] = hash;
         }
     }
-    if (px.active) storeRT(P.result, (int64_t)px.y * P.ResX + px.x, colour);
+    if (px.active) {
+        const int64_t i = (int64_t)px.y * P.ResX + px.x;
+        if (P.result.unorm8) colour = make_float4(toUnorm8(colour.x), toUnorm8(colour.y), toUnorm8(colour.z), toUnorm8(colour.w));
+        P.result.rgba[i] = colour;
+        if (ACC) {  // k_accumulate on the texel just stored
+            const float4 a = P.accumulated.rgba[i];
+            const float weight = 1.0f / (float)(P.ppFrameCount + 1);
+            float4 o;
+            o.x = saturate(a.x * (1 - weight) + colour.x * weight);
+            o.y = saturate(a.y * (1 - weight) + colour.y * weight);
+            o.z = saturate(a.z * (1 - weight) + colour.z * weight);
+            o.w = 0.0f;
+            storeRT(P.accumulated, i, o);
+        }
+    }
     writeTileSteps(P, steps);
     if (INSTR && P.waveProfile && P.waveProfileKernel == 2) writeWaveProfile(P, tStart, iters, acc);
     if (P.stats) {

@@ -43,7 +43,8 @@ static __device__ __align__(256) uint32_t scratch[NOALLOC_TABLE_WORDS + NOALLOC_
 
 struct rt_ctx_s {
     int device = 0;
-    hipStream_t stream = nullptr;
+    // The dispatch stream.  Every use goes through S(ctx), which first launches a held-back dispatch (see Deferred).
+    hipStream_t stream0 = nullptr;
     hipStream_t transferStream = nullptr;  // created by rt_transfer_stream
     hipEvent_t orderEvent[2] = {nullptr, nullptr};
     hipEvent_t marks[64] = {};
@@ -69,6 +70,24 @@ struct rt_ctx_s {
     double timeMs[IK_COUNT] = {};
     uint64_t launches[IK_COUNT] = {};
     uint64_t versionCounter = 1;
+    // A dispatch that is held back until the next call shows whether it can be merged with what follows it.
+    // TransferToOriginal, TraceRays and AccumulateFrames each touch only the thread's own pixel, and the reference issues
+    // them back to back (Main.cs:387-420): TransferToOriginal is held, a TraceRays over the same buffers, rows and grid
+    // takes its copy along (the reservoir it copies is the one TraceRays reads) and is held in turn, and an
+    // AccumulateFrames over the same Result adds its running average to the same launch.  One launch instead of three:
+    // one tail instead of three, and the copied reservoir and the stored colour are not read back from memory.
+    // Any other call - another dispatch, an upload, a readback, a sync, a stream or timing query - first launches what
+    // is held, unmerged, so the order of effects is the order of the calls.  Constants are snapshotted at dispatch as
+    // always.  Not held: instrumented variants, rt_dispatch_no_alloc, RT_FUSE=0.
+    struct Deferred {
+        int kind = 0;               // 0 nothing, 1 TransferToOriginal, 2 TraceRays (withTransfer: it carries the copy)
+        KParams P;
+        unsigned blocks = 0;
+        size_t ldsBytes = 0;
+        bool withTransfer = false;
+        BlockMap* grid = nullptr;
+    } held;
+    bool fuse = true;
     // prepared traversal data (derived from the bound scene buffers)
     struct Prep {
         float4* wide = nullptr; size_t wideBytes = 0;
@@ -134,6 +153,12 @@ int useDevice(rt_ctx ctx) {
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     return RT_OK;
 }
+void launchHeld(rt_ctx ctx);
+// The dispatch stream, for everything except the merged launches themselves: what is held back goes first.
+hipStream_t S(rt_ctx ctx) {
+    if (ctx->held.kind) launchHeld(ctx);
+    return ctx->stream0;
+}
 
 Planes planesOf(rt_buffer b) {
     Planes p;
@@ -160,8 +185,8 @@ void launchToAos(rt_buffer b, void* dst, int64_t first = 0, int64_t n = -1) {
     if (n < 0) n = b->count - first;
     if (n <= 0) return;
     const int blocks = (int)((n + 255) / 256);
-    if (b->layout == LAYOUT_RESERVOIR_RECS) hipLaunchKernelGGL(k_recs_to_aos, dim3(blocks), dim3(256), 0, b->ctx->stream, recsOf(b), (float*)dst, first, n);
-    else hipLaunchKernelGGL(k_planes_to_aos, dim3(blocks), dim3(256), 0, b->ctx->stream, planesOf(b), (float*)dst, b->layout == LAYOUT_RESERVOIR_PLANES ? 0 : 1, first, n);
+    if (b->layout == LAYOUT_RESERVOIR_RECS) hipLaunchKernelGGL(k_recs_to_aos, dim3(blocks), dim3(256), 0, S(b->ctx), recsOf(b), (float*)dst, first, n);
+    else hipLaunchKernelGGL(k_planes_to_aos, dim3(blocks), dim3(256), 0, S(b->ctx), planesOf(b), (float*)dst, b->layout == LAYOUT_RESERVOIR_PLANES ? 0 : 1, first, n);
 }
 
 // Switches a 52-byte-stride buffer between the ABI's array-of-structures layout and an internal one.
@@ -181,12 +206,12 @@ int convertLayout(rt_buffer b, int target) {
     if (target == LAYOUT_AOS) {
         launchToAos(b, tmp);
     } else if (target == LAYOUT_RESERVOIR_RECS) {
-        hipLaunchKernelGGL(k_aos_to_recs, dim3(blocks), dim3(256), 0, ctx->stream, (const float*)b->dev, recsOf(&shadow));
+        hipLaunchKernelGGL(k_aos_to_recs, dim3(blocks), dim3(256), 0, S(ctx), (const float*)b->dev, recsOf(&shadow));
     } else {
-        hipLaunchKernelGGL(k_aos_to_planes, dim3(blocks), dim3(256), 0, ctx->stream, (const float*)b->dev, planesOf(&shadow), target == LAYOUT_RESERVOIR_PLANES ? 0 : 1);
+        hipLaunchKernelGGL(k_aos_to_planes, dim3(blocks), dim3(256), 0, S(ctx), (const float*)b->dev, planesOf(&shadow), target == LAYOUT_RESERVOIR_PLANES ? 0 : 1);
     }
     hipError_t e = hipGetLastError();
-    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(S(ctx));
     if (e != hipSuccess) {
         hipError_t e2 = hipFree(tmp);
         (void)e2;
@@ -293,7 +318,7 @@ int prepareScene(rt_shader sh, int kernel, KParams& P, bool ris = false) {
             return fail(ctx, RT_ERR_NOT_PREPARED, "the traversal arrays of the bound scene buffers are not built: building them allocates; "
                                                   "dispatch kernel %d once with rt_dispatch after uploading the scene", kernel);
         pr.valid = false;
-        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        HIP_TRY(ctx, hipStreamSynchronize(S(ctx)));
         std::vector<rt_bv> bvs((size_t)bBVs->count);
         std::vector<rt_scene_object> objs((size_t)bObjs->count);
         std::vector<rt_triangle> tris(ris ? 0 : (size_t)bTris->count);
@@ -339,15 +364,15 @@ int prepareScene(rt_shader sh, int kernel, KParams& P, bool ris = false) {
         if ((rc = ensure((void**)&pr.wide, &pr.wideBytes, (size_t)bBVs->count * 64))) return rc;
         if ((rc = ensure((void**)&pr.btri, &pr.btriBytes, (size_t)bTris->count * 64))) return rc;
         if ((rc = ensure((void**)&pr.objRoot, &pr.objRootBytes, (size_t)bObjs->count * 4))) return rc;
-        hipLaunchKernelGGL(k_build_wide, dim3((unsigned)((bBVs->count + 255) / 256)), dim3(256), 0, ctx->stream,
+        hipLaunchKernelGGL(k_build_wide, dim3((unsigned)((bBVs->count + 255) / 256)), dim3(256), 0, S(ctx),
                            (const rt_bv*)bBVs->dev, bBVs->count, pr.wide);
         if (ris)
-            hipLaunchKernelGGL(k_ris_bake_tris, dim3((unsigned)((bTris->count + 255) / 256)), dim3(256), 0, ctx->stream,
+            hipLaunchKernelGGL(k_ris_bake_tris, dim3((unsigned)((bTris->count + 255) / 256)), dim3(256), 0, S(ctx),
                                (const rt_ris_tri*)bTris->dev, bTris->count, pr.btri);
         else
-            hipLaunchKernelGGL(k_bake_tris, dim3((unsigned)((bTris->count + 255) / 256)), dim3(256), 0, ctx->stream,
+            hipLaunchKernelGGL(k_bake_tris, dim3((unsigned)((bTris->count + 255) / 256)), dim3(256), 0, S(ctx),
                                (const rt_triangle*)bTris->dev, bTris->count, (const rt_vertex*)bVerts->dev, bVerts->count, pr.btri);
-        hipLaunchKernelGGL(k_obj_root_entries, dim3((unsigned)((bObjs->count + 255) / 256)), dim3(256), 0, ctx->stream,
+        hipLaunchKernelGGL(k_obj_root_entries, dim3((unsigned)((bObjs->count + 255) / 256)), dim3(256), 0, S(ctx),
                            (const rt_bv*)bBVs->dev, bBVs->count, (const rt_scene_object*)bObjs->dev, bObjs->count, pr.objRoot);
         HIP_TRY(ctx, hipGetLastError());
         // stack entry of the scene root, same rule as the device-side entryOf()
@@ -524,9 +549,9 @@ int pixelGrid(rt_ctx ctx, KParams& P, int gx, int gy, unsigned* blocks, rt_ctx_s
         m.cost = ctx->scratch + NOALLOC_TABLE_WORDS;
         m.n = m.nDyn = (regions + 7) / 8 * (8 * RT_REGION * RT_REGION);
         m.dynValid = false; m.age = 0;
-        HIP_TRY(ctx, hipMemsetAsync(m.cost, 0, (size_t)bx * by * 4 * sizeof(uint32_t), ctx->stream));
+        HIP_TRY(ctx, hipMemsetAsync(m.cost, 0, (size_t)bx * by * 4 * sizeof(uint32_t), S(ctx)));
         m.steps = nullptr; m.stepsValid = false; m.rankedBySteps = false; m.dynHits = nullptr;
-        hipLaunchKernelGGL(k_order_blocks, dim3(1), dim3(1024), 0, ctx->stream, m.cost, m.bx, m.by, m.dyn, m.nDyn, 0);
+        hipLaunchKernelGGL(k_order_blocks, dim3(1), dim3(1024), 0, S(ctx), m.cost, m.bx, m.by, m.dyn, m.nDyn, 0);
         HIP_TRY(ctx, hipGetLastError());
         P.blockMap = m.dev;
         *blocks = m.n;
@@ -542,7 +567,7 @@ int pixelGrid(rt_ctx ctx, KParams& P, int gx, int gy, unsigned* blocks, rt_ctx_s
     for (auto& m : ctx->blockMaps)
         if (m.bx == (int)bx && m.by == (int)by) return use(m);
     if (ctx->blockMaps.size() >= 16) {  // bounded: forget the oldest table once nothing can still be reading it
-        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        HIP_TRY(ctx, hipStreamSynchronize(S(ctx)));
         rt_ctx_s::BlockMap& old = ctx->blockMaps.front();
         hipError_t e = hipFree(old.dev);
         if (old.dyn) e = hipFree(old.dyn);
@@ -579,9 +604,9 @@ void reorderBlocks(rt_ctx ctx, rt_ctx_s::BlockMap* m) {
     const bool firstMeasured = measured && !m->rankedBySteps;   // the first frame after measurements exist re-ranks at once
     if (m->dynValid && !firstMeasured && (++m->age % 8) != 0) return;
     m->rankedBySteps = measured;
-    hipLaunchKernelGGL(k_order_blocks, dim3(1), dim3(1024), 0, ctx->stream, measured ? m->steps : m->cost, m->bx, m->by, m->dyn, m->nDyn, measured ? 1 : 0);
+    hipLaunchKernelGGL(k_order_blocks, dim3(1), dim3(1024), 0, S(ctx), measured ? m->steps : m->cost, m->bx, m->by, m->dyn, m->nDyn, measured ? 1 : 0);
     // the primary rays' cost follows the hit count, not the secondary rays' steps: their launch gets a ranking of its own
-    if (m->dynHits) hipLaunchKernelGGL(k_order_blocks, dim3(1), dim3(1024), 0, ctx->stream, m->cost, m->bx, m->by, m->dynHits, m->nDyn, 0);
+    if (m->dynHits) hipLaunchKernelGGL(k_order_blocks, dim3(1), dim3(1024), 0, S(ctx), m->cost, m->bx, m->by, m->dynHits, m->nDyn, 0);
     m->dynValid = true;
 }
 
@@ -590,7 +615,8 @@ struct LaunchScope {
     rt_ctx ctx;
     int ik;
     hipEvent_t start = nullptr, stop = nullptr;
-    LaunchScope(rt_ctx c, int k, KParams* P) : ctx(c), ik(k) {
+    hipStream_t stream;
+    LaunchScope(rt_ctx c, int k, KParams* P) : ctx(c), ik(k), stream(S(c)) {
         if (P) { P->stats = ctx->statsLevel > 0 ? ctx->statsDev + (size_t)k * STAT_SHARDS * 8 : nullptr; P->statsLevel = ctx->statsLevel; }
         ctx->launches[k]++;
         if (!ctx->timing || ctx->noAlloc || (ctx->timingOnly >= 0 && ctx->timingOnly != k)) return;
@@ -602,18 +628,18 @@ struct LaunchScope {
         };
         start = take();
         stop = take();
-        if (start && stop) { hipError_t e = hipEventRecord(start, ctx->stream); (void)e; }
+        if (start && stop) { hipError_t e = hipEventRecord(start, stream); (void)e; }
     }
     ~LaunchScope() {
         if (!start || !stop) return;
-        hipError_t e = hipEventRecord(stop, ctx->stream);
+        hipError_t e = hipEventRecord(stop, stream);
         (void)e;
         ctx->pending.push_back({ik, start, stop});
     }
 };
 int drainTiming(rt_ctx ctx) {
     if (ctx->pending.empty()) return RT_OK;
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(S(ctx)));
     for (auto& t : ctx->pending) {
         float ms = 0;
         if (hipEventElapsedTime(&ms, t.start, t.stop) == hipSuccess) ctx->timeMs[t.kernel] += ms;
@@ -623,6 +649,25 @@ int drainTiming(rt_ctx ctx) {
     ctx->pending.clear();
     return RT_OK;
 }
+
+// Launches what is held back (rt_ctx_s::Deferred), as it was dispatched.  `acc` = an AccumulateFrames to merge into a held
+// TraceRays: its two textures and frame count have been put into the held parameters by the caller.
+void launchHeld(rt_ctx ctx, bool acc) {
+    rt_ctx_s::Deferred h = ctx->held;
+    ctx->held.kind = 0;   // first: everything below may ask for the stream
+    if (h.kind == 1) {
+        LaunchScope ls(ctx, IK_TRANSFER, &h.P);
+        hipLaunchKernelGGL(k_transfer, dim3(h.blocks), dim3(256), 0, ctx->stream0, h.P);
+    } else if (h.kind == 2) {
+        LaunchScope ls(ctx, IK_TRACE_RAYS, &h.P);
+        if (h.withTransfer && acc) hipLaunchKernelGGL((k_trace_rays<false, true, true>), dim3(h.blocks), dim3(256), h.ldsBytes, ctx->stream0, h.P);
+        else if (h.withTransfer) hipLaunchKernelGGL((k_trace_rays<false, true, false>), dim3(h.blocks), dim3(256), h.ldsBytes, ctx->stream0, h.P);
+        else if (acc) hipLaunchKernelGGL((k_trace_rays<false, false, true>), dim3(h.blocks), dim3(256), h.ldsBytes, ctx->stream0, h.P);
+        else hipLaunchKernelGGL((k_trace_rays<false, false, false>), dim3(h.blocks), dim3(256), h.ldsBytes, ctx->stream0, h.P);
+    }
+}
+void launchHeld(rt_ctx ctx) { launchHeld(ctx, false); }
+bool mayHold(rt_ctx ctx, bool instr) { return ctx->fuse && !ctx->noAlloc && !instr && ctx->statsLevel < 2; }
 
 int dispatchReSTIR(rt_shader sh, int kernel, int gx, int gy) {
     rt_ctx ctx = sh->ctx;
@@ -676,8 +721,8 @@ int dispatchReSTIR(rt_shader sh, int kernel, int gx, int gy) {
                 if (grid) P.blockCost = grid->cost;
                 if (grid && grid->dynValid && grid->dynHits) { P.blockMap = grid->dynHits; blocks = grid->nDyn; }
                 LaunchScope ls(ctx, IK_PRIMARY, &P);
-                if (instr) hipLaunchKernelGGL(k_primary<true>, dim3(blocks), dim3(256), ldsBytes, ctx->stream, P);
-                else hipLaunchKernelGGL(k_primary<false>, dim3(blocks), dim3(256), ldsBytes, ctx->stream, P);
+                if (instr) hipLaunchKernelGGL(k_primary<true>, dim3(blocks), dim3(256), ldsBytes, S(ctx), P);
+                else hipLaunchKernelGGL(k_primary<false>, dim3(blocks), dim3(256), ldsBytes, S(ctx), P);
             }
             if (grid && grid->dyn) {  // the candidate kernel and everything after it run heaviest regions first
                 reorderBlocks(ctx, grid);
@@ -687,8 +732,8 @@ int dispatchReSTIR(rt_shader sh, int kernel, int gx, int gy) {
             }
             {
                 LaunchScope ls(ctx, IK_CANDIDATES, &P);
-                if (instr) hipLaunchKernelGGL(k_candidates<true>, dim3(blocks), dim3(256), ldsBytes, ctx->stream, P);
-                else hipLaunchKernelGGL(k_candidates<false>, dim3(blocks), dim3(256), ldsBytes, ctx->stream, P);
+                if (instr) hipLaunchKernelGGL(k_candidates<true>, dim3(blocks), dim3(256), ldsBytes, S(ctx), P);
+                else hipLaunchKernelGGL(k_candidates<false>, dim3(blocks), dim3(256), ldsBytes, S(ctx), P);
             }
             break;
         }
@@ -697,7 +742,7 @@ int dispatchReSTIR(rt_shader sh, int kernel, int gx, int gy) {
             if ((rc = needRecs(sh, kernel, "CandidatesB", P.candB)) || (rc = checkCount(P.candB, "CandidatesB"))) return rc;
             if ((rc = needTex(sh, kernel, "DepthBuffer", true, X, Y, P.depth))) return rc;
             if (!blocks) break;
-            { LaunchScope ls(ctx, IK_SPATIAL, &P); hipLaunchKernelGGL(k_spatial, dim3(blocks), dim3(256), 0, ctx->stream, P); }
+            { LaunchScope ls(ctx, IK_SPATIAL, &P); hipLaunchKernelGGL(k_spatial, dim3(blocks), dim3(256), 0, S(ctx), P); }
             break;
         }
         case 2: {  // TransferToOriginal
@@ -705,7 +750,13 @@ int dispatchReSTIR(rt_shader sh, int kernel, int gx, int gy) {
             if ((rc = needRecs(sh, kernel, "CandidatesB", P.candB)) || (rc = checkCount(P.candB, "CandidatesB"))) return rc;
             if ((rc = needTex(sh, kernel, "DepthBuffer", true, X, Y, P.depth))) return rc;
             if (!blocks) break;
-            { LaunchScope ls(ctx, IK_TRANSFER, &P); hipLaunchKernelGGL(k_transfer, dim3(blocks), dim3(256), 0, ctx->stream, P); }
+            if (mayHold(ctx, instr)) {  // held: a TraceRays that follows takes the copy along
+                S(ctx);
+                ctx->held.kind = 1; ctx->held.P = P; ctx->held.blocks = blocks; ctx->held.grid = grid; ctx->held.withTransfer = false;
+            } else {
+                LaunchScope ls(ctx, IK_TRANSFER, &P);
+                hipLaunchKernelGGL(k_transfer, dim3(blocks), dim3(256), 0, S(ctx), P);
+            }
             break;
         }
         case 3: {  // TemporalReuse
@@ -715,7 +766,7 @@ int dispatchReSTIR(rt_shader sh, int kernel, int gx, int gy) {
             if ((rc = needTex(sh, kernel, "RayHitPointsA", false, X, Y, P.hitA))) return rc;
             if ((rc = needTex(sh, kernel, "RayHitPointsB", false, X, Y, P.hitB))) return rc;
             if (!blocks) break;
-            { LaunchScope ls(ctx, IK_TEMPORAL, &P); hipLaunchKernelGGL(k_temporal, dim3(blocks), dim3(256), 0, ctx->stream, P); }
+            { LaunchScope ls(ctx, IK_TEMPORAL, &P); hipLaunchKernelGGL(k_temporal, dim3(blocks), dim3(256), 0, S(ctx), P); }
             break;
         }
         case 4: {  // TraceRays
@@ -729,10 +780,20 @@ int dispatchReSTIR(rt_shader sh, int kernel, int gx, int gy) {
             if (!blocks) break;
             size_t ldsBytes = (size_t)WAVES_PER_BLOCK * P.stackDepth * 64 * 4;
             if (grid && grid->steps) { P.blockSteps = grid->steps; grid->stepsValid = true; }
-            {
+            if (mayHold(ctx, instr)) {
+                // a held TransferToOriginal over the same buffers, rows and table becomes part of this launch
+                const rt_ctx_s::Deferred& h = ctx->held;
+                const bool takeCopy = h.kind == 1 && h.grid == grid && h.blocks == blocks && h.P.blockMap == P.blockMap && h.P.cand.q == P.cand.q &&
+                                      h.P.cand.count == P.cand.count && h.P.candB.count >= P.cand.count && h.P.row0 == P.row0 && h.P.row1 == P.row1 &&
+                                      h.P.ResX == P.ResX && h.P.ResY == P.ResY;
+                if (takeCopy) { P.candB = h.P.candB; P.depth = h.P.depth; ctx->held.kind = 0; }
+                else S(ctx);
+                ctx->held.kind = 2; ctx->held.P = P; ctx->held.blocks = blocks; ctx->held.ldsBytes = ldsBytes; ctx->held.grid = grid;
+                ctx->held.withTransfer = takeCopy;
+            } else {
                 LaunchScope ls(ctx, IK_TRACE_RAYS, &P);
-                if (instr) hipLaunchKernelGGL(k_trace_rays<true>, dim3(blocks), dim3(256), ldsBytes, ctx->stream, P);
-                else hipLaunchKernelGGL(k_trace_rays<false>, dim3(blocks), dim3(256), ldsBytes, ctx->stream, P);
+                if (instr) hipLaunchKernelGGL((k_trace_rays<true>), dim3(blocks), dim3(256), ldsBytes, S(ctx), P);
+                else hipLaunchKernelGGL((k_trace_rays<false>), dim3(blocks), dim3(256), ldsBytes, S(ctx), P);
             }
             break;
         }
@@ -801,8 +862,8 @@ int dispatchRIS(rt_shader sh, int kernel, int gx, int gy) {
         {
             if (grid) P.blockCost = grid->cost;
             LaunchScope ls(ctx, IK_RIS_PRIMARY, &P);
-            if (instr) hipLaunchKernelGGL(k_ris_primary<true>, dim3(blocks), dim3(256), ldsBytes, ctx->stream, P);
-            else hipLaunchKernelGGL(k_ris_primary<false>, dim3(blocks), dim3(256), ldsBytes, ctx->stream, P);
+            if (instr) hipLaunchKernelGGL(k_ris_primary<true>, dim3(blocks), dim3(256), ldsBytes, S(ctx), P);
+            else hipLaunchKernelGGL(k_ris_primary<false>, dim3(blocks), dim3(256), ldsBytes, S(ctx), P);
         }
         if (grid && grid->dyn) {
             reorderBlocks(ctx, grid);
@@ -812,14 +873,14 @@ int dispatchRIS(rt_shader sh, int kernel, int gx, int gy) {
         }
         {
             LaunchScope ls(ctx, IK_RIS_CANDIDATES, &P);
-            hipLaunchKernelGGL(k_ris_candidates, dim3(blocks), dim3(256), 0, ctx->stream, P);
+            hipLaunchKernelGGL(k_ris_candidates, dim3(blocks), dim3(256), 0, S(ctx), P);
         }
     } else {
         if ((rc = needTex(sh, kernel, "Result", false, X, Y, P.result))) return rc;
         if (!blocks) return RT_OK;
         LaunchScope ls(ctx, IK_RIS_TRACE_RAYS, &P);
-        if (instr) hipLaunchKernelGGL(k_ris_trace_rays<true>, dim3(blocks), dim3(256), ldsBytes, ctx->stream, P);
-        else hipLaunchKernelGGL(k_ris_trace_rays<false>, dim3(blocks), dim3(256), ldsBytes, ctx->stream, P);
+        if (instr) hipLaunchKernelGGL(k_ris_trace_rays<true>, dim3(blocks), dim3(256), ldsBytes, S(ctx), P);
+        else hipLaunchKernelGGL(k_ris_trace_rays<false>, dim3(blocks), dim3(256), ldsBytes, S(ctx), P);
     }
     HIP_TRY(ctx, hipGetLastError());
     return RT_OK;
@@ -840,7 +901,7 @@ int dispatchPreCalc(rt_shader sh, int kernel, int gx) {
         uint32_t n = trisNum < covered ? trisNum : (uint32_t)covered;
         {
             LaunchScope ls(ctx, IK_RIS_CALC_NORMALS, nullptr);
-            hipLaunchKernelGGL(k_ris_calc_tri_normals, dim3((unsigned)gx), dim3(256), 0, ctx->stream, (rt_ris_tri*)rTris->dev, rTris->count,
+            hipLaunchKernelGGL(k_ris_calc_tri_normals, dim3((unsigned)gx), dim3(256), 0, S(ctx), (rt_ris_tri*)rTris->dev, rTris->count,
                                (const rt_scene_object*)rObjs->dev, rObjs->count, n);
         }
         HIP_TRY(ctx, hipGetLastError());
@@ -857,7 +918,7 @@ int dispatchPreCalc(rt_shader sh, int kernel, int gx) {
     uint32_t n = trianglesNum < covered ? trianglesNum : (uint32_t)covered;
     {
         LaunchScope ls(ctx, IK_CALC_NORMALS, nullptr);
-        hipLaunchKernelGGL(k_calc_tri_normals, dim3((unsigned)gx), dim3(256), 0, ctx->stream, (rt_triangle*)bTris->dev, bTris->count,
+        hipLaunchKernelGGL(k_calc_tri_normals, dim3((unsigned)gx), dim3(256), 0, S(ctx), (rt_triangle*)bTris->dev, bTris->count,
                            (const rt_vertex*)bVerts->dev, bVerts->count, n);
     }
     HIP_TRY(ctx, hipGetLastError());
@@ -881,9 +942,22 @@ int dispatchPostProc(rt_shader sh, int kernel, int gx, int gy) {
     P.result.rgba = (float4*)res->dev; P.accumulated.rgba = (float4*)acc->dev;
     P.accumulated.unorm8 = acc->format == RT_FORMAT_RGBA8_UNORM;
     unsigned blocks = 0;
-    int rc = pixelGrid(ctx, P, gx, gy, &blocks);
+    rt_ctx_s::BlockMap* grid = nullptr;
+    int rc = pixelGrid(ctx, P, gx, gy, &blocks, &grid);
     if (rc) return rc;
-    if (blocks) { LaunchScope ls(ctx, IK_ACCUMULATE, &P); hipLaunchKernelGGL(k_accumulate, dim3(blocks), dim3(256), 0, ctx->stream, P); }
+    {
+        // a held TraceRays that writes this Result over the same rows and table takes the running average along
+        rt_ctx_s::Deferred& h = ctx->held;
+        if (blocks && h.kind == 2 && ctx->fuse && !ctx->noAlloc && ctx->statsLevel < 2 && h.grid == grid && h.blocks == blocks && h.P.blockMap == P.blockMap &&
+            h.P.result.rgba == P.result.rgba && h.P.ResX == P.ResX && h.P.ResY == P.ResY && h.P.row0 == P.row0 && h.P.row1 == P.row1) {
+            h.P.accumulated = P.accumulated;
+            h.P.ppFrameCount = P.ppFrameCount;
+            launchHeld(ctx, true);
+            HIP_TRY(ctx, hipGetLastError());
+            return RT_OK;
+        }
+    }
+    if (blocks) { LaunchScope ls(ctx, IK_ACCUMULATE, &P); hipLaunchKernelGGL(k_accumulate, dim3(blocks), dim3(256), 0, S(ctx), P); }
     HIP_TRY(ctx, hipGetLastError());
     return RT_OK;
 }
@@ -903,9 +977,11 @@ int rt_create(int device_id, rt_ctx* out) {
     if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) return RT_ERR_NO_DEVICE;  // the only code object in this library
     rt_ctx ctx = new rt_ctx_s;
     ctx->device = device_id;
-    if (hipSetDevice(device_id) != hipSuccess || hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess ||
+    static const bool fuse = [] { const char* e = getenv("RT_FUSE"); return e ? atoi(e) != 0 : true; }();
+    ctx->fuse = fuse;
+    if (hipSetDevice(device_id) != hipSuccess || hipStreamCreateWithFlags(&ctx->stream0, hipStreamNonBlocking) != hipSuccess ||
         hipMalloc((void**)&ctx->statsDev, IK_COUNT * STAT_SHARDS * 8 * sizeof(unsigned long long)) != hipSuccess ||
-        hipMemsetAsync(ctx->statsDev, 0, IK_COUNT * STAT_SHARDS * 8 * sizeof(unsigned long long), ctx->stream) != hipSuccess) {
+        hipMemsetAsync(ctx->statsDev, 0, IK_COUNT * STAT_SHARDS * 8 * sizeof(unsigned long long), S(ctx)) != hipSuccess) {
         delete ctx;
         return RT_ERR_NO_DEVICE;
     }
@@ -921,7 +997,7 @@ int rt_create(int device_id, rt_ctx* out) {
 void rt_destroy(rt_ctx ctx) {
     if (!ctx) return;
     hipError_t e = hipSetDevice(ctx->device);
-    e = hipStreamSynchronize(ctx->stream);
+    e = hipStreamSynchronize(S(ctx));
     for (auto& pr : ctx->prep) {
         if (pr.wide) e = hipFree(pr.wide);
         if (pr.btri) e = hipFree(pr.btri);
@@ -934,14 +1010,14 @@ void rt_destroy(rt_ctx ctx) {
     for (auto ev : ctx->orderEvent) if (ev) e = hipEventDestroy(ev);
     for (auto ev : ctx->marks) if (ev) e = hipEventDestroy(ev);
     if (ctx->transferStream) { e = hipStreamSynchronize(ctx->transferStream); e = hipStreamDestroy(ctx->transferStream); }
-    e = hipStreamDestroy(ctx->stream);
+    e = hipStreamDestroy(ctx->stream0);
     (void)e;
     delete ctx;
 }
 
 int rt_sync(rt_ctx ctx) {
     if (!ctx) return RT_ERR_INVALID_ARG;
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(S(ctx)));
     if (ctx->transferStream) HIP_TRY(ctx, hipStreamSynchronize(ctx->transferStream));
     return RT_OK;
 }
@@ -963,7 +1039,7 @@ int rt_stream_order(rt_ctx ctx, int first) {
     if (!rt_transfer_stream(ctx)) return RT_ERR_NO_DEVICE;
     hipEvent_t& ev = ctx->orderEvent[first];
     if (!ev) HIP_TRY(ctx, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
-    hipStream_t from = first == 0 ? ctx->stream : ctx->transferStream, to = first == 0 ? ctx->transferStream : ctx->stream;
+    hipStream_t from = first == 0 ? S(ctx) : ctx->transferStream, to = first == 0 ? ctx->transferStream : S(ctx);
     HIP_TRY(ctx, hipEventRecord(ev, from));
     HIP_TRY(ctx, hipStreamWaitEvent(to, ev, 0));
     return RT_OK;
@@ -974,7 +1050,7 @@ int rt_mark(rt_ctx ctx, int stream, int slot) {
     if (rc) return rc;
     if (stream == 1 && !rt_transfer_stream(ctx)) return RT_ERR_NO_DEVICE;
     if (!ctx->marks[slot]) HIP_TRY(ctx, hipEventCreate(&ctx->marks[slot]));
-    HIP_TRY(ctx, hipEventRecord(ctx->marks[slot], stream == 0 ? ctx->stream : ctx->transferStream));
+    HIP_TRY(ctx, hipEventRecord(ctx->marks[slot], stream == 0 ? S(ctx) : ctx->transferStream));
     return RT_OK;
 }
 int rt_mark_elapsed(rt_ctx ctx, int a, int b, double* ms) {
@@ -990,7 +1066,7 @@ int rt_mark_elapsed(rt_ctx ctx, int a, int b, double* ms) {
     return RT_OK;
 }
 const char* rt_last_error(rt_ctx ctx) { return ctx ? ctx->err.c_str() : "null context"; }
-void* rt_stream(rt_ctx ctx) { return ctx ? (void*)ctx->stream : nullptr; }
+void* rt_stream(rt_ctx ctx) { return ctx ? (void*)S(ctx) : nullptr; }
 
 int rt_set_row_band(rt_ctx ctx, int row0, int row1) {
     if (!ctx) return RT_ERR_INVALID_ARG;
@@ -1114,7 +1190,7 @@ int rt_buffer_create(rt_ctx ctx, int64_t count, int stride, rt_buffer* out) {
     b->version = ctx->versionCounter++;
     b->dev = nullptr;
     hipError_t e = hipMalloc(&b->dev, b->bytes);
-    if (e == hipSuccess) e = hipMemsetAsync(b->dev, 0, b->bytes, ctx->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(b->dev, 0, b->bytes, S(ctx));
     if (e != hipSuccess) {
         if (b->dev) { hipError_t e2 = hipFree(b->dev); (void)e2; }
         delete b;
@@ -1132,8 +1208,8 @@ int rt_buffer_set_data(rt_buffer b, const void* src, size_t bytes) {
     if (rc) return rc;
     if ((rc = convertLayout(b, LAYOUT_AOS))) return rc;
     // synchronous copy: the caller may reuse `src` as soon as this returns
-    HIP_TRY(ctx, hipMemcpyAsync(b->dev, src, bytes, hipMemcpyHostToDevice, ctx->stream));
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(b->dev, src, bytes, hipMemcpyHostToDevice, S(ctx)));
+    HIP_TRY(ctx, hipStreamSynchronize(S(ctx)));
     b->version = ctx->versionCounter++;
     return RT_OK;
 }
@@ -1145,16 +1221,16 @@ int rt_buffer_get_data(rt_buffer b, void* dst, size_t bytes) {
     int rc = useDevice(ctx);
     if (rc) return rc;
     if (b->layout == LAYOUT_AOS) {
-        HIP_TRY(ctx, hipMemcpyAsync(dst, b->dev, bytes, hipMemcpyDeviceToHost, ctx->stream));
-        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        HIP_TRY(ctx, hipMemcpyAsync(dst, b->dev, bytes, hipMemcpyDeviceToHost, S(ctx)));
+        HIP_TRY(ctx, hipStreamSynchronize(S(ctx)));
         return RT_OK;
     }
     void* tmp = nullptr;
     HIP_TRY(ctx, hipMalloc(&tmp, b->bytes));
     launchToAos(b, tmp);
     hipError_t e = hipGetLastError();
-    if (e == hipSuccess) e = hipMemcpyAsync(dst, tmp, bytes, hipMemcpyDeviceToHost, ctx->stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(dst, tmp, bytes, hipMemcpyDeviceToHost, S(ctx));
+    if (e == hipSuccess) e = hipStreamSynchronize(S(ctx));
     hipError_t e2 = hipFree(tmp);
     (void)e2;
     if (e != hipSuccess) return fail(ctx, RT_ERR_NO_DEVICE, "buffer readback failed: %s", hipGetErrorString(e));
@@ -1171,16 +1247,16 @@ int rt_buffer_get_range(rt_buffer b, void* dst, int64_t first, int64_t count) {
     if (rc) return rc;
     const size_t bytes = (size_t)count * b->stride;
     if (b->layout == LAYOUT_AOS) {
-        HIP_TRY(ctx, hipMemcpyAsync(dst, (const char*)b->dev + (size_t)first * b->stride, bytes, hipMemcpyDeviceToHost, ctx->stream));
-        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        HIP_TRY(ctx, hipMemcpyAsync(dst, (const char*)b->dev + (size_t)first * b->stride, bytes, hipMemcpyDeviceToHost, S(ctx)));
+        HIP_TRY(ctx, hipStreamSynchronize(S(ctx)));
         return RT_OK;
     }
     void* tmp = nullptr;
     HIP_TRY(ctx, hipMalloc(&tmp, bytes));
     launchToAos(b, tmp, first, count);
     hipError_t e = hipGetLastError();
-    if (e == hipSuccess) e = hipMemcpyAsync(dst, tmp, bytes, hipMemcpyDeviceToHost, ctx->stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(dst, tmp, bytes, hipMemcpyDeviceToHost, S(ctx));
+    if (e == hipSuccess) e = hipStreamSynchronize(S(ctx));
     hipError_t e2 = hipFree(tmp);
     (void)e2;
     if (e != hipSuccess) return fail(ctx, RT_ERR_NO_DEVICE, "buffer readback failed: %s", hipGetErrorString(e));
@@ -1190,7 +1266,7 @@ int rt_buffer_get_range(rt_buffer b, void* dst, int64_t first, int64_t count) {
 void rt_buffer_release(rt_buffer b) {
     if (!b) return;
     hipError_t e = hipSetDevice(b->ctx->device);
-    e = hipStreamSynchronize(b->ctx->stream);
+    e = hipStreamSynchronize(S(b->ctx));
     if (b->dev) e = hipFree(b->dev);
     (void)e;
     delete b;
@@ -1211,7 +1287,7 @@ int rt_texture_create(rt_ctx ctx, int w, int h, rt_format format, rt_texture* ou
     t->bytes = (size_t)w * h * (format == RT_FORMAT_R32F ? 4 : 16);
     t->dev = nullptr;
     hipError_t e = hipMalloc(&t->dev, t->bytes);
-    if (e == hipSuccess) e = hipMemsetAsync(t->dev, 0, t->bytes, ctx->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(t->dev, 0, t->bytes, S(ctx));
     if (e != hipSuccess) {
         if (t->dev) { hipError_t e2 = hipFree(t->dev); (void)e2; }
         delete t;
@@ -1231,20 +1307,20 @@ int rt_texture_set_data(rt_texture t, const void* src, size_t bytes) {
         if (bytes != (size_t)n * 4) return fail(ctx, RT_ERR_INVALID_ARG, "RGBA8 texture upload must be %lld bytes", (long long)n * 4);
         void* tmp = nullptr;
         HIP_TRY(ctx, hipMalloc(&tmp, bytes));
-        hipError_t e = hipMemcpyAsync(tmp, src, bytes, hipMemcpyHostToDevice, ctx->stream);
+        hipError_t e = hipMemcpyAsync(tmp, src, bytes, hipMemcpyHostToDevice, S(ctx));
         if (e == hipSuccess) {
-            hipLaunchKernelGGL(k_rgba8_to_f32, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, (const uint8_t*)tmp, (float4*)t->dev, n);
+            hipLaunchKernelGGL(k_rgba8_to_f32, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, S(ctx), (const uint8_t*)tmp, (float4*)t->dev, n);
             e = hipGetLastError();
         }
-        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(S(ctx));
         hipError_t e2 = hipFree(tmp);
         (void)e2;
         if (e != hipSuccess) return fail(ctx, RT_ERR_NO_DEVICE, "texture upload failed: %s", hipGetErrorString(e));
         return RT_OK;
     }
     if (bytes != t->bytes) return fail(ctx, RT_ERR_INVALID_ARG, "texture upload must be %zu bytes", t->bytes);
-    HIP_TRY(ctx, hipMemcpyAsync(t->dev, src, bytes, hipMemcpyHostToDevice, ctx->stream));
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(t->dev, src, bytes, hipMemcpyHostToDevice, S(ctx)));
+    HIP_TRY(ctx, hipStreamSynchronize(S(ctx)));
     t->version = ctx->versionCounter++;
     return RT_OK;
 }
@@ -1255,8 +1331,8 @@ int rt_texture_get_data(rt_texture t, void* dst, size_t bytes) {
     if (bytes > t->bytes) return fail(ctx, RT_ERR_INVALID_ARG, "texture readback of %zu bytes from %zu", bytes, t->bytes);
     int rc = useDevice(ctx);
     if (rc) return rc;
-    HIP_TRY(ctx, hipMemcpyAsync(dst, t->dev, bytes, hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(dst, t->dev, bytes, hipMemcpyDeviceToHost, S(ctx)));
+    HIP_TRY(ctx, hipStreamSynchronize(S(ctx)));
     return RT_OK;
 }
 
@@ -1268,15 +1344,15 @@ int rt_texture_get_rows(rt_texture t, void* dst, int row0, int row1) {
     int rc = useDevice(ctx);
     if (rc) return rc;
     const size_t rowBytes = (size_t)t->w * (t->format == RT_FORMAT_R32F ? 4 : 16);
-    HIP_TRY(ctx, hipMemcpyAsync(dst, (const char*)t->dev + rowBytes * row0, rowBytes * (size_t)(row1 - row0), hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(dst, (const char*)t->dev + rowBytes * row0, rowBytes * (size_t)(row1 - row0), hipMemcpyDeviceToHost, S(ctx)));
+    HIP_TRY(ctx, hipStreamSynchronize(S(ctx)));
     return RT_OK;
 }
 
 void rt_texture_release(rt_texture t) {
     if (!t) return;
     hipError_t e = hipSetDevice(t->ctx->device);
-    e = hipStreamSynchronize(t->ctx->stream);
+    e = hipStreamSynchronize(S(t->ctx));
     if (t->dev) e = hipFree(t->dev);
     (void)e;
     delete t;
@@ -1287,6 +1363,7 @@ int rt_buffer_map_rows(rt_buffer b, int width, int row0, int row1, rt_segment ou
     rt_ctx ctx = b->ctx;
     if (width < 1 || row0 < 0 || row1 < row0 || (int64_t)row1 * width > b->count)
         return fail(ctx, RT_ERR_INVALID_ARG, "rows [%d,%d) of width %d are outside the buffer", row0, row1, width);
+    S(ctx);   // whoever reads through these pointers orders itself against the stream: nothing may still be held back
     const size_t first = (size_t)row0 * width, n = (size_t)(row1 - row0) * width;
     char* base = (char*)b->dev;
     if (b->layout == LAYOUT_AOS) {
@@ -1305,6 +1382,7 @@ int rt_buffer_map_rows(rt_buffer b, int width, int row0, int row1, rt_segment ou
 int rt_texture_map_rows(rt_texture t, int row0, int row1, rt_segment* out) {
     if (!t || !out) return RT_ERR_INVALID_ARG;
     if (row0 < 0 || row1 < row0 || row1 > t->h) return fail(t->ctx, RT_ERR_INVALID_ARG, "rows [%d,%d) are outside the texture", row0, row1);
+    S(t->ctx);
     const size_t texel = t->format == RT_FORMAT_R32F ? 4 : 16;
     out->ptr = (char*)t->dev + (size_t)row0 * t->w * texel;
     out->bytes = (size_t)(row1 - row0) * t->w * texel;
@@ -1316,16 +1394,16 @@ int rt_enable_stats(rt_ctx ctx, int level) {
     int rc = useDevice(ctx);
     if (rc) return rc;
     if (level != ctx->statsLevel)  // counters restart whenever the level changes
-        HIP_TRY(ctx, hipMemsetAsync(ctx->statsDev, 0, IK_COUNT * STAT_SHARDS * 8 * sizeof(unsigned long long), ctx->stream));
+        HIP_TRY(ctx, hipMemsetAsync(ctx->statsDev, 0, IK_COUNT * STAT_SHARDS * 8 * sizeof(unsigned long long), S(ctx)));
     ctx->statsLevel = level;
     return RT_OK;
 }
 static int fetchStats(rt_ctx ctx, int ik, bool reset, unsigned long long h[8]) {
     unsigned long long raw[STAT_SHARDS * 8];
     unsigned long long* src = ctx->statsDev + (size_t)ik * STAT_SHARDS * 8;
-    HIP_TRY(ctx, hipMemcpyAsync(raw, src, sizeof raw, hipMemcpyDeviceToHost, ctx->stream));
-    if (reset) HIP_TRY(ctx, hipMemsetAsync(src, 0, sizeof raw, ctx->stream));
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(raw, src, sizeof raw, hipMemcpyDeviceToHost, S(ctx)));
+    if (reset) HIP_TRY(ctx, hipMemsetAsync(src, 0, sizeof raw, S(ctx)));
+    HIP_TRY(ctx, hipStreamSynchronize(S(ctx)));
     for (int c = 0; c < 8; c++) { h[c] = 0; for (int s = 0; s < STAT_SHARDS; s++) h[c] += raw[s * 8 + c]; }
     return RT_OK;
 }
@@ -1384,8 +1462,8 @@ int rt_profile_reset(rt_ctx ctx) {
     if (rc) return rc;
     if ((rc = drainTiming(ctx))) return rc;
     for (int i = 0; i < IK_COUNT; i++) { ctx->timeMs[i] = 0; ctx->launches[i] = 0; }
-    HIP_TRY(ctx, hipMemsetAsync(ctx->statsDev, 0, IK_COUNT * STAT_SHARDS * 8 * sizeof(unsigned long long), ctx->stream));
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, hipMemsetAsync(ctx->statsDev, 0, IK_COUNT * STAT_SHARDS * 8 * sizeof(unsigned long long), S(ctx)));
+    HIP_TRY(ctx, hipStreamSynchronize(S(ctx)));
     return RT_OK;
 }
 int rt_profile_get(rt_ctx ctx, const char* kernel_name, rt_kernel_profile* out) {

@@ -29,7 +29,11 @@ def read(path):
         m = re.match(r"(?:void )?rtn::(k_\w+)(?:<([\w, ]+)>)? dispatches=(\d+) (.*)", line.strip())
         if not m or m.group(1) not in NAMES or (m.group(2) and m.group(2).split(",")[0].strip() != "false"):
             continue   # the instrumented (<true>) variants only run in the untimed counter frames
-        out[NAMES[m.group(1)]] = {k: float(v) for k, v in (kv.split("=") for kv in m.group(4).split())}
+        vals = {k: float(v) for k, v in (kv.split("=") for kv in m.group(4).split())}
+        vals["_dispatches"] = int(m.group(3))
+        name = NAMES[m.group(1)]
+        if name not in out or vals["_dispatches"] > out[name]["_dispatches"]:   # merged and unmerged variants: the one the frames ran
+            out[name] = vals
     return out
 
 
