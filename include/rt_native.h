@@ -13,7 +13,7 @@
  *  - One caller thread per context.  Dispatches and uploads are enqueued in call order on one HIP stream and are
  *    asynchronous; rt_sync() and the *_get_data() calls wait for them.  Constants are snapshotted at dispatch.
  *  - A dispatch may be held back until the next call on its context shows whether the two can run as one launch
- *    (TransferToOriginal + TraceRays + AccumulateFrames issued back to back do).  Every call that could observe the
+ *    (InitialTrace + TemporalReuse, and TransferToOriginal + TraceRays + AccumulateFrames, issued back to back do).  Every call that could observe the
  *    difference - another dispatch, an upload, a readback, rt_sync, the stream, mark, map and statistics calls -
  *    launches what is held first, so effects keep the order of the calls; a host that only dispatches and then waits on
  *    the stream by other means must call rt_sync (or rt_stream) once after its last dispatch.

@@ -825,7 +825,42 @@ DEV v2 GenerateCandidateWeight(const KParams& P, float sqrDst, float hitAngleDot
     return {weight, brdf};
 }
 
-template <bool INSTR>
+// TemporalReuse for one pixel that holds a hit (RS:592-640): `thisFrame` is the pixel's reservoir of this frame.  Stores
+// the pixel's TemporalFrameBuffer record; returns whether `thisFrame` (merged or not) also replaces the Candidates record.
+DEV bool temporalMerge(const KParams& P, const Pixel& px, Reservoir& thisFrame) {
+    const uint32_t idx = (uint32_t)px.x, idy = (uint32_t)px.y;
+    uint32_t state = idy * (uint32_t)P.ResX + idx + P.FrameRand;
+    const uint32_t pixelIndex = (uint32_t)P.ResX * idy + idx;
+    v2 uv = {(float)idx / (float)P.ResX, (float)idy / (float)P.ResY};
+    v3 worldFocalPos = GetFocalPos(P, uv);
+    v2 lastUV = GetLastUV(P, worldFocalPos);
+    float dx = uv.x - lastUV.x, dy = uv.y - lastUV.y;
+    if (__builtin_sqrtf(dx * dx + dy * dy) > P.TemporalPrecisionThreshold) {
+        storeReservoir(P.temporal, pixelIndex, thisFrame);
+        return false;
+    }
+    const int64_t i = (int64_t)idy * P.ResX + idx;
+    float4 a = P.hitA.rgba[i], b = P.hitB.rgba[i];
+    float movement = length(V3(a.x, a.y, a.z) - V3(b.x, b.y, b.z));
+    if (movement <= P.PixelMovementThreshold) {
+        Reservoir last = loadReservoir(P.temporal, pixelIndex);
+        float adjustedThis = thisFrame.totWeights * (1.0f - P.TemporalReuseWeight);
+        float adjustedLast = last.totWeights * P.TemporalReuseWeight;
+        float totWeights = adjustedThis + adjustedLast;
+        if (weightedRand(adjustedLast, totWeights, state)) {
+            thisFrame.dir = last.dir;
+            thisFrame.chosenWeight = last.chosenWeight;
+            thisFrame.hitPoint = last.hitPoint;
+        }
+        thisFrame.totWeights = avg(thisFrame.totWeights * (1.0f - P.TemporalReuseWeight), last.totWeights * P.TemporalReuseWeight);
+        thisFrame.totCandidates = avg(thisFrame.totCandidates * (1.0f - P.TemporalReuseWeight), last.totCandidates * P.TemporalReuseWeight);
+    }
+    storeReservoir(P.temporal, pixelIndex, thisFrame);
+    return true;
+}
+// TEMP: the launch also makes TemporalReuse's merge (RS:586-641) for its pixel, on the reservoir it has just produced
+// (or, for a pixel whose depth holds a hit that its HitInfo does not, on the stored one), and stores the result once.
+template <bool INSTR, bool TEMP = false>
 __global__ __launch_bounds__(256, RT_MIN_WAVES) void k_candidates(const KParams P) {
     extern __shared__ uint32_t lds[];
     const Pixel px = pixelOfThread(P);
@@ -838,6 +873,8 @@ __global__ __launch_bounds__(256, RT_MIN_WAVES) void k_candidates(const KParams 
     if (px.active) {
         const uint32_t idx = (uint32_t)px.x, idy = (uint32_t)px.y;
         const int64_t i = (int64_t)idy * P.ResX + idx;
+        bool made = false;           // this launch produced the pixel's reservoir
+        Reservoir res = emptyReservoir();
         if (P.hit.p0[i].w != INF()) {  // pixels whose primary ray missed need only this one plane
             const HitInfo hitInfo = loadHit(P, i);
             // the two draws of randPointInCircle precede this in the reference's single kernel
@@ -866,7 +903,6 @@ __global__ __launch_bounds__(256, RT_MIN_WAVES) void k_candidates(const KParams 
 
             v3 dst = worldPoint - hitInfo.hitPoint;
             v3 dir = normalize(dst);
-            Reservoir res;
             if (dot(hitInfo.normal, dir) < 0) {
                 res = emptyReservoir();
             } else {
@@ -888,8 +924,13 @@ __global__ __launch_bounds__(256, RT_MIN_WAVES) void k_candidates(const KParams 
                 res.dir = dir; res.hitPoint = hitInfo.hitPoint; res.normal = hitInfo.normal;
                 res.brdf = wb.y; res.chosenWeight = wb.x; res.totWeights = wb.x; res.totCandidates = 1;
             }
-            if ((int64_t)pixelIndex < P.cand.count) storeReservoir(P.cand, pixelIndex, res);
+            made = (int64_t)pixelIndex < P.cand.count;
         }
+        if (TEMP && P.FrameCount != 0 && P.depth.r[i] != INF()) {
+            if (!made) res = loadReservoir(P.cand, i);
+            if (temporalMerge(P, px, res)) made = true;
+        }
+        if (made) storeReservoir(P.cand, i, res);
     }
     if (INSTR && P.waveProfile && P.waveProfileKernel == 1) writeWaveProfile(P, tStart, rays ? t.iters : 0, t);
     if (P.stats) {
@@ -917,39 +958,9 @@ __global__ __launch_bounds__(256) void k_temporal(const KParams P) {
     if (mask != 0) {  // wave-uniform: the record moves below are made by the whole wave
         const int lane = (int)(threadIdx.x & 63);
         const int x0 = px.x - (lane & 7), y0 = px.y - (lane >> 3);
-        const uint32_t idx = (uint32_t)px.x, idy = (uint32_t)px.y;
-        uint32_t state = idy * (uint32_t)P.ResX + idx + P.FrameRand;
-        const uint32_t pixelIndex = (uint32_t)P.ResX * idy + idx;
         Reservoir thisFrame = coopLoadReservoir(P, P.cand, x0, y0, mask, stage);
         bool storeCand = false;
-        if (active) {
-            v2 uv = {(float)idx / (float)P.ResX, (float)idy / (float)P.ResY};
-            v3 worldFocalPos = GetFocalPos(P, uv);
-            v2 lastUV = GetLastUV(P, worldFocalPos);
-            float dx = uv.x - lastUV.x, dy = uv.y - lastUV.y;
-            if (__builtin_sqrtf(dx * dx + dy * dy) > P.TemporalPrecisionThreshold) {
-                storeReservoir(P.temporal, pixelIndex, thisFrame);
-            } else {
-                const int64_t i = (int64_t)idy * P.ResX + idx;
-                float4 a = P.hitA.rgba[i], b = P.hitB.rgba[i];
-                float movement = length(V3(a.x, a.y, a.z) - V3(b.x, b.y, b.z));
-                if (movement <= P.PixelMovementThreshold) {
-                    Reservoir last = loadReservoir(P.temporal, pixelIndex);
-                    float adjustedThis = thisFrame.totWeights * (1.0f - P.TemporalReuseWeight);
-                    float adjustedLast = last.totWeights * P.TemporalReuseWeight;
-                    float totWeights = adjustedThis + adjustedLast;
-                    if (weightedRand(adjustedLast, totWeights, state)) {
-                        thisFrame.dir = last.dir;
-                        thisFrame.chosenWeight = last.chosenWeight;
-                        thisFrame.hitPoint = last.hitPoint;
-                    }
-                    thisFrame.totWeights = avg(thisFrame.totWeights * (1.0f - P.TemporalReuseWeight), last.totWeights * P.TemporalReuseWeight);
-                    thisFrame.totCandidates = avg(thisFrame.totCandidates * (1.0f - P.TemporalReuseWeight), last.totCandidates * P.TemporalReuseWeight);
-                }
-                storeCand = true;
-                storeReservoir(P.temporal, pixelIndex, thisFrame);
-            }
-        }
+        if (active) storeCand = temporalMerge(P, px, thisFrame);
         coopStoreReservoir(P, P.cand, x0, y0, __builtin_amdgcn_ballot_w64(storeCand), stage, thisFrame);
     }
     if (P.stats && P.statsLevel >= 2) waveAdd(P.stats + ST_ACTIVE, active ? 1u : 0u);

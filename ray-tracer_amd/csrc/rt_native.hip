@@ -8,6 +8,7 @@
 #include "rt_kernels_ris.hip"
 
 #include <cstdarg>
+#include <cstddef>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -80,7 +81,8 @@ struct rt_ctx_s {
     // is held, unmerged, so the order of effects is the order of the calls.  Constants are snapshotted at dispatch as
     // always.  Not held: instrumented variants, rt_dispatch_no_alloc, RT_FUSE=0.
     struct Deferred {
-        int kind = 0;               // 0 nothing, 1 TransferToOriginal, 2 TraceRays (withTransfer: it carries the copy)
+        int kind = 0;               // 0 nothing, 1 TransferToOriginal, 2 TraceRays (withTransfer: it carries the copy),
+                                    // 3 InitialTrace's candidate kernel
         KParams P;
         unsigned blocks = 0;
         size_t ldsBytes = 0;
@@ -650,14 +652,19 @@ int drainTiming(rt_ctx ctx) {
     return RT_OK;
 }
 
-// Launches what is held back (rt_ctx_s::Deferred), as it was dispatched.  `acc` = an AccumulateFrames to merge into a held
-// TraceRays: its two textures and frame count have been put into the held parameters by the caller.
+// Launches what is held back (rt_ctx_s::Deferred), as it was dispatched.  `acc` = the dispatch that follows is merged into
+// it (AccumulateFrames into a held TraceRays, TemporalReuse into a held candidate kernel): the caller has put what that
+// dispatch binds into the held parameters.
 void launchHeld(rt_ctx ctx, bool acc) {
     rt_ctx_s::Deferred h = ctx->held;
     ctx->held.kind = 0;   // first: everything below may ask for the stream
     if (h.kind == 1) {
         LaunchScope ls(ctx, IK_TRANSFER, &h.P);
         hipLaunchKernelGGL(k_transfer, dim3(h.blocks), dim3(256), 0, ctx->stream0, h.P);
+    } else if (h.kind == 3) {
+        LaunchScope ls(ctx, IK_CANDIDATES, &h.P);
+        if (acc) hipLaunchKernelGGL((k_candidates<false, true>), dim3(h.blocks), dim3(256), h.ldsBytes, ctx->stream0, h.P);
+        else hipLaunchKernelGGL((k_candidates<false, false>), dim3(h.blocks), dim3(256), h.ldsBytes, ctx->stream0, h.P);
     } else if (h.kind == 2) {
         LaunchScope ls(ctx, IK_TRACE_RAYS, &h.P);
         if (h.withTransfer && acc) hipLaunchKernelGGL((k_trace_rays<false, true, true>), dim3(h.blocks), dim3(256), h.ldsBytes, ctx->stream0, h.P);
@@ -730,10 +737,14 @@ int dispatchReSTIR(rt_shader sh, int kernel, int gx, int gy) {
                 blocks = grid->nDyn;
                 P.blockCost = nullptr;
             }
-            {
+            if (mayHold(ctx, instr)) {  // held: a TemporalReuse that follows becomes part of the launch
+                S(ctx);
+                ctx->held.kind = 3; ctx->held.P = P; ctx->held.blocks = blocks; ctx->held.ldsBytes = ldsBytes; ctx->held.grid = grid;
+                ctx->held.withTransfer = false;
+            } else {
                 LaunchScope ls(ctx, IK_CANDIDATES, &P);
-                if (instr) hipLaunchKernelGGL(k_candidates<true>, dim3(blocks), dim3(256), ldsBytes, S(ctx), P);
-                else hipLaunchKernelGGL(k_candidates<false>, dim3(blocks), dim3(256), ldsBytes, S(ctx), P);
+                if (instr) hipLaunchKernelGGL((k_candidates<true>), dim3(blocks), dim3(256), ldsBytes, S(ctx), P);
+                else hipLaunchKernelGGL((k_candidates<false>), dim3(blocks), dim3(256), ldsBytes, S(ctx), P);
             }
             break;
         }
@@ -766,6 +777,18 @@ int dispatchReSTIR(rt_shader sh, int kernel, int gx, int gy) {
             if ((rc = needTex(sh, kernel, "RayHitPointsA", false, X, Y, P.hitA))) return rc;
             if ((rc = needTex(sh, kernel, "RayHitPointsB", false, X, Y, P.hitB))) return rc;
             if (!blocks) break;
+            {
+                // a held candidate kernel over the same buffers, rows, table and constants takes the merge along
+                rt_ctx_s::Deferred& h = ctx->held;
+                const size_t c0 = offsetof(KParams, MaxBVHDepth), c1 = offsetof(KParams, ppFrameCount);
+                if (h.kind == 3 && mayHold(ctx, instr) && h.grid == grid && h.blocks == blocks && h.P.blockMap == P.blockMap && h.P.row0 == P.row0 &&
+                    h.P.row1 == P.row1 && h.P.cand.q == P.cand.q && h.P.cand.count == P.cand.count && h.P.depth.r == P.depth.r &&
+                    memcmp((const char*)&h.P + c0, (const char*)&P + c0, c1 - c0) == 0) {
+                    h.P.temporal = P.temporal; h.P.hitA = P.hitA; h.P.hitB = P.hitB;
+                    launchHeld(ctx, true);
+                    break;
+                }
+            }
             { LaunchScope ls(ctx, IK_TEMPORAL, &P); hipLaunchKernelGGL(k_temporal, dim3(blocks), dim3(256), 0, S(ctx), P); }
             break;
         }

@@ -1,6 +1,6 @@
-"""TransferToOriginal, TraceRays and AccumulateFrames issued back to back run as one launch (the library holds a dispatch
-until the next call shows whether the two can be merged); anything in between - here a sync - makes them run one by
-one.  Both orders of events must leave every buffer and render target identical, and the launch counts must show
+"""InitialTrace's candidate kernel + TemporalReuse, and TransferToOriginal + TraceRays + AccumulateFrames, issued back
+to back run as one launch each (the library holds a dispatch until the next call shows whether the two can be merged);
+anything in between - here a sync - makes them run one by one.  Both orders of events must leave every buffer and render target identical, and the launch counts must show
 which path ran."""
 import numpy as np
 import pytest
@@ -33,6 +33,9 @@ def test_merged_and_separate_launches_agree(gpu_ctx, scene_small, unorm8):
         gpu_ctx.sync()
         n = launches(gpu_ctx)
         assert n.get("trace_rays", 0) == frames and n.get("transfer", 0) == 0 and n.get("accumulate", 0) == 0, n
+        # (the first TemporalReuse of a context converts TemporalFrameBuffer to the library's layout, which launches
+        # what is held: at most that one runs on its own)
+        assert n.get("candidates", 0) == frames and n.get("temporal", 0) <= 1, n
         got = {**{k: merged.buffer(k) for k in BUFS}, **{k: merged.texture(k) for k in TEXS}}
 
         gpu_ctx.profile_reset()
@@ -45,6 +48,7 @@ def test_merged_and_separate_launches_agree(gpu_ctx, scene_small, unorm8):
                 gpu_ctx.sync()
         n = launches(gpu_ctx)
         assert n.get("trace_rays", 0) == frames and n.get("transfer", 0) == frames and n.get("accumulate", 0) == frames, n
+        assert n.get("candidates", 0) == frames and n.get("temporal", 0) == frames, n
         gpu_ctx.profile_enable(False)
         for k in BUFS:
             assert np.array_equal(h.bits(got[k]), h.bits(apart.buffer(k))), k
