@@ -86,3 +86,52 @@ def test_a_readback_between_the_dispatches_sees_the_copy(gpu_ctx, scene_small):
             assert np.array_equal(h.bits(drv.texture("AccumulatedResult")), h.bits(orc.tex["AccumulatedResult"]))
     finally:
         drv.close()
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_random_calls_between_dispatches(gpu_ctx, scene_small, seed):
+    """Whatever is called between the dispatches of a frame - nothing, a sync, a partial readback, a band set to the same
+    rows, a statistics query - the frames must come out as when every dispatch is waited for."""
+    rng = np.random.default_rng(seed)
+    cfg = h.small_config(88, 64)
+    cfg.SpatialReuseIterations = int(rng.integers(1, 4))      # odd counts end with TransferToOriginal, even ones do not
+    loose, strict = rt.Driver(gpu_ctx, cfg, scene_small), rt.Driver(gpu_ctx, cfg, scene_small)
+
+    def between(drv):
+        k = int(rng.integers(0, 6))
+        if k == 1:
+            gpu_ctx.sync()
+        elif k == 2:
+            drv.buffer_rows("Candidates", 8, 16)
+        elif k == 3:
+            drv.texture_rows("Result", 0, 8)
+        elif k == 4:
+            gpu_ctx.set_row_band(0, 0)
+        elif k == 5:
+            gpu_ctx.profile()
+
+    def frame(drv, hook):
+        drv.update_per_frame(); hook(drv)
+        drv.run_stage(0); hook(drv)
+        drv.run_stage(1); hook(drv)
+        for i in range(cfg.SpatialReuseIterations):
+            drv.run_spatial_pass(i); hook(drv)
+        if cfg.SpatialReuseIterations % 2 == 1:
+            drv.run_transfer(); hook(drv)
+        drv.run_stage(3); hook(drv)
+        drv.run_post_processing(); hook(drv)
+
+    try:
+        for _ in range(5):
+            frame(loose, between)
+        for _ in range(5):
+            frame(strict, lambda d: gpu_ctx.sync())
+        gpu_ctx.sync()
+        for k in BUFS:
+            assert np.array_equal(h.bits(loose.buffer(k)), h.bits(strict.buffer(k))), k
+        for k in TEXS:
+            assert np.array_equal(h.bits(loose.texture(k)), h.bits(strict.texture(k))), k
+    finally:
+        gpu_ctx.set_row_band(0, 0)
+        loose.close()
+        strict.close()
