@@ -248,11 +248,13 @@ __global__ __launch_bounds__(256) void k_ris_candidates(const KParams P) {
 // =====================================================================================================
 // TraceRays (RI:503-559; RayDirFromCandidates RI:416-453; Trace RI:455-501)
 // =====================================================================================================
-template <bool INSTR>
+// ACC: the launch also makes AccumulateFrames' running average (PostProcesser.compute) of the colour it stores.
+template <bool INSTR, bool ACC = false>
 __global__ __launch_bounds__(256, RT_MIN_WAVES) void k_ris_trace_rays(const KParams P) {
     extern __shared__ uint32_t lds[];
     const Pixel px = pixelOfThread(P);
     uint32_t rays = 0, pops = 0, bvc = 0, objv = 0, trii = 0, tric = 0;
+    float4 colour = make_float4(0, 0, 0, 0);
     if (px.active) {
         const uint32_t idx = (uint32_t)px.x, idy = (uint32_t)px.y;
         uint32_t state = idy * (uint32_t)P.ResX + idx + (uint32_t)P.risFrameRand;
@@ -277,11 +279,11 @@ __global__ __launch_bounds__(256, RT_MIN_WAVES) void k_ris_trace_rays(const KPar
         const v3 risDir = V3(chosen.x, chosen.y, chosen.z);
 
         if (first.dst == INF()) {
-            storeRT(P.result, i, make_float4(0, 0, 0, 0));
+            colour = make_float4(0, 0, 0, 0);
         } else if (anyZero(risDir)) {
             const rt_ris_material material = loadRisMaterial(P, first.materialIndex);
             v3 col = V3(material.color) * material.brightness / sqr(first.dst);
-            storeRT(P.result, i, make_float4(col.x, col.y, col.z, 0.0f));
+            colour = make_float4(col.x, col.y, col.z, 0.0f);
         } else {
             const float correctionWeight = risW * (float)P.RaysPerPixel;
             v3 combined = V3(0, 0, 0);
@@ -321,8 +323,20 @@ __global__ __launch_bounds__(256, RT_MIN_WAVES) void k_ris_trace_rays(const KPar
                 combined = combined + incomingLight;
             }
             combined = combined / correctionWeight;
-            storeRT(P.result, i, make_float4(combined.x, combined.y, combined.z, 0.0f));
+            colour = make_float4(combined.x, combined.y, combined.z, 0.0f);
             if (INSTR && P.records && rays) P.records[i * RECORD_DWORDS + 7] = hash;
+        }
+        if (P.result.unorm8) colour = make_float4(toUnorm8(colour.x), toUnorm8(colour.y), toUnorm8(colour.z), toUnorm8(colour.w));
+        P.result.rgba[i] = colour;
+        if (ACC) {  // k_accumulate on the texel just stored
+            const float4 a = P.accumulated.rgba[i];
+            const float weight = 1.0f / (float)(P.ppFrameCount + 1);
+            float4 o;
+            o.x = saturate(a.x * (1 - weight) + colour.x * weight);
+            o.y = saturate(a.y * (1 - weight) + colour.y * weight);
+            o.z = saturate(a.z * (1 - weight) + colour.z * weight);
+            o.w = 0.0f;
+            storeRT(P.accumulated, i, o);
         }
     }
     if (P.stats) {

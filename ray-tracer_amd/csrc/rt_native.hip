@@ -82,7 +82,7 @@ struct rt_ctx_s {
     // always.  Not held: instrumented variants, rt_dispatch_no_alloc, RT_FUSE=0.
     struct Deferred {
         int kind = 0;               // 0 nothing, 1 TransferToOriginal, 2 TraceRays (withTransfer: it carries the copy),
-                                    // 3 InitialTrace's candidate kernel
+                                    // 3 InitialTrace's candidate kernel, 4 the RIS project's TraceRays
         KParams P;
         unsigned blocks = 0;
         size_t ldsBytes = 0;
@@ -665,6 +665,10 @@ void launchHeld(rt_ctx ctx, bool acc) {
         LaunchScope ls(ctx, IK_CANDIDATES, &h.P);
         if (acc) hipLaunchKernelGGL((k_candidates<false, true>), dim3(h.blocks), dim3(256), h.ldsBytes, ctx->stream0, h.P);
         else hipLaunchKernelGGL((k_candidates<false, false>), dim3(h.blocks), dim3(256), h.ldsBytes, ctx->stream0, h.P);
+    } else if (h.kind == 4) {
+        LaunchScope ls(ctx, IK_RIS_TRACE_RAYS, &h.P);
+        if (acc) hipLaunchKernelGGL((k_ris_trace_rays<false, true>), dim3(h.blocks), dim3(256), h.ldsBytes, ctx->stream0, h.P);
+        else hipLaunchKernelGGL((k_ris_trace_rays<false, false>), dim3(h.blocks), dim3(256), h.ldsBytes, ctx->stream0, h.P);
     } else if (h.kind == 2) {
         LaunchScope ls(ctx, IK_TRACE_RAYS, &h.P);
         if (h.withTransfer && acc) hipLaunchKernelGGL((k_trace_rays<false, true, true>), dim3(h.blocks), dim3(256), h.ldsBytes, ctx->stream0, h.P);
@@ -901,9 +905,15 @@ int dispatchRIS(rt_shader sh, int kernel, int gx, int gy) {
     } else {
         if ((rc = needTex(sh, kernel, "Result", false, X, Y, P.result))) return rc;
         if (!blocks) return RT_OK;
-        LaunchScope ls(ctx, IK_RIS_TRACE_RAYS, &P);
-        if (instr) hipLaunchKernelGGL(k_ris_trace_rays<true>, dim3(blocks), dim3(256), ldsBytes, S(ctx), P);
-        else hipLaunchKernelGGL(k_ris_trace_rays<false>, dim3(blocks), dim3(256), ldsBytes, S(ctx), P);
+        if (mayHold(ctx, instr)) {  // held: an AccumulateFrames that follows becomes part of the launch
+            S(ctx);
+            ctx->held.kind = 4; ctx->held.P = P; ctx->held.blocks = blocks; ctx->held.ldsBytes = ldsBytes; ctx->held.grid = grid;
+            ctx->held.withTransfer = false;
+        } else {
+            LaunchScope ls(ctx, IK_RIS_TRACE_RAYS, &P);
+            if (instr) hipLaunchKernelGGL((k_ris_trace_rays<true>), dim3(blocks), dim3(256), ldsBytes, S(ctx), P);
+            else hipLaunchKernelGGL((k_ris_trace_rays<false>), dim3(blocks), dim3(256), ldsBytes, S(ctx), P);
+        }
     }
     HIP_TRY(ctx, hipGetLastError());
     return RT_OK;
@@ -971,7 +981,7 @@ int dispatchPostProc(rt_shader sh, int kernel, int gx, int gy) {
     {
         // a held TraceRays that writes this Result over the same rows and table takes the running average along
         rt_ctx_s::Deferred& h = ctx->held;
-        if (blocks && h.kind == 2 && ctx->fuse && !ctx->noAlloc && ctx->statsLevel < 2 && h.grid == grid && h.blocks == blocks && h.P.blockMap == P.blockMap &&
+        if (blocks && (h.kind == 2 || h.kind == 4) && ctx->fuse && !ctx->noAlloc && ctx->statsLevel < 2 && h.grid == grid && h.blocks == blocks && h.P.blockMap == P.blockMap &&
             h.P.result.rgba == P.result.rgba && h.P.ResX == P.ResX && h.P.ResY == P.ResY && h.P.row0 == P.row0 && h.P.row1 == P.row1) {
             h.P.accumulated = P.accumulated;
             h.P.ppFrameCount = P.ppFrameCount;
