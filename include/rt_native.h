@@ -16,7 +16,11 @@
  *    (InitialTrace + TemporalReuse, and TransferToOriginal + TraceRays + AccumulateFrames, issued back to back do).  Every call that could observe the
  *    difference - another dispatch, an upload, a readback, rt_sync, the stream, mark, map and statistics calls -
  *    launches what is held first, so effects keep the order of the calls; a host that only dispatches and then waits on
- *    the stream by other means must call rt_sync (or rt_stream) once after its last dispatch.
+ *    the stream by other means must call rt_flush (or rt_sync, or rt_stream) once after its last dispatch.
+ *    rt_set_fusion(ctx, 0) switches the holding off for a context (the environment variable RT_FUSE=0 for a process).
+ *  - A kernel launch that fails is reported as RT_ERR_LAUNCH with the kernel's name in rt_last_error().  Because a held
+ *    dispatch is launched by a later call, its failure may be returned by that call instead (any entry point that
+ *    returns a status, rt_flush and rt_sync included) - once, and never lost.
  *  - There is no CPU fallback: rt_create() fails when no gfx950 device is usable.
  */
 #ifndef RT_NATIVE_H
@@ -42,7 +46,9 @@ typedef enum {
     RT_ERR_UNBOUND = -4,       /* a dispatch needs a buffer/texture/constant that was never set */
     RT_ERR_BAD_SCENE = -5,     /* scene buffers failed validation (index out of range, BVH too deep, cycle) */
     RT_ERR_LIMIT = -6,         /* a size exceeds a documented limit of an entry point */
-    RT_ERR_NOT_PREPARED = -7   /* rt_dispatch_no_alloc only: the dispatch would have to allocate device memory */
+    RT_ERR_NOT_PREPARED = -7,  /* rt_dispatch_no_alloc only: the dispatch would have to allocate device memory */
+    RT_ERR_LAUNCH = -8,        /* a kernel launch failed; rt_last_error() names the kernel (may surface one call late, see above) */
+    RT_ERR_BUSY = -9           /* rt_dispatch_no_alloc only: another context's dispatch still uses the GPU's shared scratch array */
 } rt_status;
 
 typedef enum {
@@ -65,8 +71,17 @@ void rt_destroy(rt_ctx ctx);
 /* Waits for all work enqueued on the context (Unity has no explicit equivalent; readbacks imply it). */
 int rt_sync(rt_ctx ctx);
 const char* rt_last_error(rt_ctx ctx);
-/* The HIP stream (hipStream_t) the context enqueues on, for callers that time or order work against it. */
+/* The HIP stream (hipStream_t) the context enqueues on, for callers that time or order work against it.  Launches a
+ * held dispatch first, like rt_flush. */
 void* rt_stream(rt_ctx ctx);
+/* Launches a dispatch that is being held back for merging (see the conventions above) and returns without waiting.
+ * A host that keeps the stream from an earlier rt_stream() call and waits on it by its own means calls this after
+ * the last dispatch of a frame.  No counterpart in the reference. */
+int rt_flush(rt_ctx ctx);
+/* enabled = 0: every dispatch is launched by the call that makes it (nothing is held or merged); 1 (the default
+ * unless RT_FUSE=0 is in the environment): consecutive dispatches that can run as one launch do.  Results are
+ * bit-identical either way.  No counterpart in the reference. */
+int rt_set_fusion(rt_ctx ctx, int enabled);
 
 /* Multi-GPU image sharding (no counterpart in the reference, which is single-GPU): restricts every per-pixel
  * kernel of this context to image rows [row0, row1).  Pixel coordinates, RNG seeds and buffer indexing stay
@@ -108,7 +123,8 @@ int rt_dispatch(rt_shader sh, int kernel, int groups_x, int groups_y, int groups
  *    back into the ABI layout (rt_buffer_get_data does not).
  *  - Launches are not timed (rt_profile_enable is ignored for them); work counters are kept as usual.
  *  - All contexts on one GPU share the array: calls that overlap in time on one GPU (different contexts, hence
- *    different streams) race on it.  Calls on one context are ordered by its stream. */
+ *    different streams) would race on it, so a call made while ANOTHER context's rt_dispatch_no_alloc launches are still
+ *    in flight on that GPU fails with RT_ERR_BUSY and launches nothing.  Calls on one context are ordered by its stream. */
 int rt_dispatch_no_alloc(rt_shader sh, int kernel, int groups_x, int groups_y, int groups_z);
 
 /* ComputeShader.EnableKeyword / DisableKeyword (Main.cs:252-257): "VIS_REUSE", "WEIGHT_RECALC", "BRDF".
@@ -155,7 +171,9 @@ int rt_buffer_get_data(rt_buffer buf, void* dst, size_t bytes);
  * partial readback: elements [first, first + count) in the reference's layout (the reference itself only reads whole
  * buffers; tests at 4K read the rows they compare). */
 int rt_buffer_get_range(rt_buffer buf, void* dst, int64_t first, int64_t count);
-/* ComputeBuffer.Release (ComputeHelper.cs:203-214); NULL is ignored. */
+/* ComputeBuffer.Release (ComputeHelper.cs:203-214, Main.cs:275 releases every buffer before a scene reload); NULL is
+ * ignored.  Waits for enqueued work, then removes the handle from every binding of the context's shaders: a dispatch
+ * that still needs it fails with RT_ERR_UNBOUND until a buffer is bound under that name again. */
 void rt_buffer_release(rt_buffer buf);
 int64_t rt_buffer_count(rt_buffer buf);
 int rt_buffer_stride(rt_buffer buf);
@@ -171,6 +189,7 @@ int rt_texture_set_data(rt_texture tex, const void* src, size_t bytes);
 int rt_texture_get_data(rt_texture tex, void* dst, size_t bytes);
 /* Rows [row0, row1) only (Texture2D.ReadPixels with a source rectangle), fp32 texels. */
 int rt_texture_get_rows(rt_texture tex, void* dst, int row0, int row1);
+/* RenderTexture.Release (Main.cs:512); NULL is ignored.  Unbinds the handle like rt_buffer_release. */
 void rt_texture_release(rt_texture tex);
 
 /* ---- multi-GPU row access (no counterpart in the reference) ----------------------------------------------- */

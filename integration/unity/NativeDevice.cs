@@ -27,6 +27,13 @@ public static class NativeDevice
     /// <summary>Waits for every dispatch and upload enqueued so far.</summary>
     public static void Sync() => RtNative.Check(RtNative.rt_sync(Ctx));
 
+    /// <summary>Launches a dispatch the library still holds back for merging, without waiting: call at the end of
+    /// OnRenderImage when nothing else (a readback, Sync) follows the last Dispatch of the frame.</summary>
+    public static void Flush() => RtNative.Check(RtNative.rt_flush(Ctx));
+
+    /// <summary>false: every Dispatch launches at once (no merged launches); results are identical either way.</summary>
+    public static void SetFusion(bool enabled) => RtNative.Check(RtNative.rt_set_fusion(Ctx, enabled ? 1 : 0));
+
     /// <summary>Multi-GPU: restricts every per-pixel kernel to image rows [row0, row1); row1 &lt;= 0 restores full frames.</summary>
     public static void SetRowBand(int row0, int row1) => RtNative.Check(RtNative.rt_set_row_band(Ctx, row0, row1));
 

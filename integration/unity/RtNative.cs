@@ -4,7 +4,7 @@
 using System;
 using System.Runtime.InteropServices;
 
-public enum RtStatus { Ok = 0, InvalidArg = -1, NoDevice = -2, OutOfMemory = -3, Unbound = -4, BadScene = -5, Limit = -6, NotPrepared = -7 }
+public enum RtStatus { Ok = 0, InvalidArg = -1, NoDevice = -2, OutOfMemory = -3, Unbound = -4, BadScene = -5, Limit = -6, NotPrepared = -7, Launch = -8, Busy = -9 }
 public enum RtFormat { R32F = 1, RGBA32F = 2, RGBA8Unorm = 3 }
 
 [StructLayout(LayoutKind.Sequential)]
@@ -29,6 +29,8 @@ internal static class RtNative
     [DllImport(Lib)] public static extern int rt_sync(IntPtr ctx);
     [DllImport(Lib)] public static extern IntPtr rt_last_error(IntPtr ctx);
     [DllImport(Lib)] public static extern IntPtr rt_stream(IntPtr ctx);
+    [DllImport(Lib)] public static extern int rt_flush(IntPtr ctx);
+    [DllImport(Lib)] public static extern int rt_set_fusion(IntPtr ctx, int enabled);
     [DllImport(Lib)] public static extern int rt_set_row_band(IntPtr ctx, int row0, int row1);
 
     // shaders

@@ -64,6 +64,7 @@ def native_lib():
         sig = {
             "rt_create": (ci, [ci, C.POINTER(vp)]), "rt_destroy": (None, [vp]), "rt_sync": (ci, [vp]),
             "rt_last_error": (cs, [vp]), "rt_stream": (vp, [vp]), "rt_transfer_stream": (vp, [vp]),
+            "rt_flush": (ci, [vp]), "rt_set_fusion": (ci, [vp, ci]),
             "rt_stream_order": (ci, [vp, ci]), "rt_mark": (ci, [vp, ci, ci]), "rt_mark_elapsed": (ci, [vp, ci, ci, C.POINTER(C.c_double)]), "rt_set_row_band": (ci, [vp, ci, ci]),
             "rt_shader_open": (ci, [vp, cs, C.POINTER(vp)]), "rt_shader_close": (None, [vp]),
             "rt_find_kernel": (ci, [vp, cs]), "rt_dispatch": (ci, [vp, ci, ci, ci, ci]),
@@ -190,6 +191,8 @@ def host_lib():
             "rth_scene_add_material": (ci, [vp, C.POINTER(_MaterialInput)]), "rth_scene_add_mesh": (ci, [vp, vp]),
             "rth_scene_add_material_textured": (ci, [vp, C.POINTER(_MaterialInput), C.POINTER(_TextureInput)]),
             "rth_scene_add_object": (ci, [vp, ci, fp, fp, fp, ci, ci]), "rth_scene_build": (ci, [vp, ci]),
+            "rth_scene_set_object_transform": (ci, [vp, ci, fp, fp, fp]), "rth_scene_rebuild": (ci, [vp, ci]),
+            "rth_main_reload": (ci, [vp, C.POINTER(MainConfig)]), "rth_ris_main_reload": (ci, [vp]),
             "rth_scene_get": (ci, [vp, C.POINTER(_SceneData)]), "rth_scene_save_json": (ci, [vp, cs]),
             "rth_scene_load_json": (ci, [vp, cs, cs, C.c_char_p, ci]), "rth_world_to_local": (None, [fp, fp, fp, fp, fp]),
             "rth_view_space_dims": (None, [C.c_float, ci, ci, fp]), "rth_camera_matrices": (None, [fp, fp, fp, fp]),
@@ -339,6 +342,23 @@ class Scene:
         self._data = d
         return self
 
+    def set_object_transform(self, object_index, position, euler_deg, scale):
+        """A GameObject moved (object_index as returned by add_object); takes effect with the next rebuild()."""
+        if host_lib().rth_scene_set_object_transform(self.h, object_index, _f3(position), _f3(euler_deg), _f3(scale)) != 0:
+            raise NativeError("rth_scene_set_object_transform failed")
+
+    def rebuild(self, keep_old_scene_bvh=True):
+        """ConstructScene again on the built scene (a reload): mesh BVHs are kept, the per-object data, the scene BVH
+        and the light list are made anew.  keep_old_scene_bvh: the ReSTIR project's behaviour (the old scene BVH stays
+        in BVs, unreferenced); False: the RIS project's."""
+        if host_lib().rth_scene_rebuild(self.h, 1 if keep_old_scene_bvh else 0) != 0:
+            raise NativeError("rth_scene_rebuild failed")
+        d = _SceneData()
+        if host_lib().rth_scene_get(self.h, C.byref(d)) != 0:
+            raise NativeError("rth_scene_get failed")
+        self._data = d
+        return self
+
     def save_json(self, folder):
         """Writes the reference's JSON scene cache (FileLoader.cs:26-44) into an existing folder."""
         if host_lib().rth_scene_save_json(self.h, folder.encode()) != 0:
@@ -403,6 +423,13 @@ class RtContext:
 
     def stream(self):
         return self.lib.rt_stream(self.h)
+
+    def flush(self):
+        """Launches a dispatch that is held back for merging, without waiting."""
+        self.check(self.lib.rt_flush(self.h), "rt_flush")
+
+    def set_fusion(self, enabled):
+        self.check(self.lib.rt_set_fusion(self.h, 1 if enabled else 0), "rt_set_fusion")
 
     def set_row_band(self, row0, row1):
         self.check(self.lib.rt_set_row_band(self.h, row0, row1), "rt_set_row_band")
@@ -512,7 +539,15 @@ class Driver:
         self._check(self.lib.rth_main_render_frame(self.h), "render_frame")
 
     def update_per_frame(self):
+        """Main.Update: UpdatePerFrame, then a requested reload."""
         self._check(self.lib.rth_main_update_per_frame(self.h), "update_per_frame")
+
+    def reload(self, cfg=None):
+        """Requests DoUpdateSettings + DoReloadData (an inspector change or a moved scene object): the next frame's
+        Update re-runs UpdateSettings(true).  Call scene.rebuild() first if objects moved."""
+        self._check(self.lib.rth_main_reload(self.h, C.byref(cfg) if cfg is not None else None), "reload")
+        if cfg is not None:
+            self.cfg = cfg
 
     def run_stage(self, stage):
         self._check(self.lib.rth_main_run_stage(self.h, stage), f"run_stage({stage})")
@@ -590,6 +625,10 @@ class RisDriver:
 
     def update_per_frame(self):
         self._check(self.lib.rth_ris_main_update_per_frame(self.h), "update_per_frame")
+
+    def reload(self):
+        """DoUpdateSettings: the next frame's Update re-runs UpdateSettings -> SetData."""
+        self._check(self.lib.rth_ris_main_reload(self.h), "reload")
 
     def run_stage(self, stage):
         self._check(self.lib.rth_ris_main_run_stage(self.h, stage), f"run_stage({stage})")

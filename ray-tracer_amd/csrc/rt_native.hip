@@ -12,7 +12,9 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <iterator>
 #include <map>
+#include <mutex>
 #include <string>
 #include <algorithm>
 #include <vector>
@@ -41,6 +43,13 @@ constexpr unsigned NOALLOC_MAX_REGIONS = ORDER_MAX_REGIONS;                     
 constexpr size_t NOALLOC_TABLE_WORDS = (size_t)NOALLOC_MAX_REGIONS * RT_REGION * RT_REGION;    // one word per 16x16-pixel block
 constexpr size_t NOALLOC_COST_WORDS = NOALLOC_TABLE_WORDS * 4;                                 // one word per 8x8-pixel tile
 static __device__ __align__(256) uint32_t scratch[NOALLOC_TABLE_WORDS + NOALLOC_COST_WORDS];   // 1.25 MiB
+
+struct rt_ctx_s;
+// The context whose rt_dispatch_no_alloc last used each GPU's scratch array (guarded by scratchMutex): a call from
+// another context is refused while that one's launches are still in flight.
+constexpr int SCRATCH_MAX_DEVICES = 64;
+static std::mutex scratchMutex;
+static rt_ctx_s* scratchOwner[SCRATCH_MAX_DEVICES] = {};
 
 struct rt_ctx_s {
     int device = 0;
@@ -90,7 +99,14 @@ struct rt_ctx_s {
         BlockMap* grid = nullptr;
     } held;
     bool fuse = true;
-    // prepared traversal data (derived from the bound scene buffers)
+    // Status of a launch whose dispatch call had already returned (a held dispatch is launched by a later call), kept
+    // until the next int-returning entry point hands it to the caller (see finish()).
+    int stickyRc = 0;
+    std::string stickyMsg;
+    std::vector<rt_shader> shaders;   // the open shaders of this context: releasing a buffer or texture unbinds it from them
+    hipEvent_t noAllocDone = nullptr; // recorded after every rt_dispatch_no_alloc: tells when this context has left the shared scratch
+    // prepared traversal data (derived from the bound scene buffers): a small cache, least recently used entry replaced,
+    // so that several shaders with different scene buffers on one context do not rebuild each other's arrays
     struct Prep {
         float4* wide = nullptr; size_t wideBytes = 0;
         float4* btri = nullptr; size_t btriBytes = 0;
@@ -100,8 +116,13 @@ struct rt_ctx_s {
         uint32_t sceneStart = 0xffffffffu;
         uint32_t sceneRootEntry = 0;
         int stackDepth = 0;
+        bool ris = false;
         bool valid = false;
-    } prep[2];  // [0] ReSTIR project's scene buffers, [1] RIS project's
+        uint64_t lastUse = 0;
+    };
+    static constexpr size_t MAX_PREPS = 4;
+    std::vector<Prep> preps;
+    uint64_t prepClock = 0;
 };
 
 struct rt_buffer_s {
@@ -154,6 +175,31 @@ int fail(rt_ctx ctx, int code, const char* fmt, ...) {
 int useDevice(rt_ctx ctx) {
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     return RT_OK;
+}
+// Checks the launch just made.  A failure is kept in the context (the first one wins) until finish() returns it: the
+// launch of a held dispatch happens inside a later call, possibly one that cannot return a status.
+void checkLaunch(rt_ctx ctx, const char* kernelName) {
+    const hipError_t e = hipGetLastError();
+    if (e == hipSuccess || ctx->stickyRc) return;
+    char buf[256];
+    snprintf(buf, sizeof buf, "launch of kernel '%s' failed: %s", kernelName, hipGetErrorString(e));
+    ctx->stickyRc = RT_ERR_LAUNCH;
+    ctx->stickyMsg = buf;
+}
+// Return value of an entry point that ended well: a launch failure recorded since the last report, or RT_OK.
+#define LAUNCH_TRY(ctx, name)                          \
+    do {                                               \
+        checkLaunch(ctx, name);                        \
+        if ((ctx)->stickyRc) return finish(ctx);       \
+    } while (0)
+int finish(rt_ctx ctx);
+int finish(rt_ctx ctx) {
+    if (!ctx->stickyRc) return RT_OK;
+    const int rc = ctx->stickyRc;
+    ctx->err = ctx->stickyMsg;
+    ctx->stickyRc = 0;
+    ctx->stickyMsg.clear();
+    return rc;
 }
 void launchHeld(rt_ctx ctx);
 // The dispatch stream, for everything except the merged launches themselves: what is held back goes first.
@@ -311,15 +357,29 @@ int prepareScene(rt_shader sh, int kernel, KParams& P, bool ris = false) {
             return fail(ctx, RT_ERR_INVALID_ARG, "scene buffer strides must be BVs 32, Triangles 28, Vertices 20, SceneObjects 168, Materials 108");
     }
     const uint32_t sceneStart = cWord(sh, "SceneBVHStartIndex");
-    auto& pr = ctx->prep[ris ? 1 : 0];
-    const bool fresh = pr.valid && pr.vBVs == bBVs->version && pr.vTris == bTris->version && pr.vVerts == bVerts->version &&
-                       pr.vObjs == bObjs->version && pr.pBVs == bBVs->dev && pr.pTris == bTris->dev && pr.pVerts == bVerts->dev &&
-                       pr.pObjs == bObjs->dev && pr.sceneStart == sceneStart;
+    auto matches = [&](const rt_ctx_s::Prep& c) {
+        return c.valid && c.ris == ris && c.vBVs == bBVs->version && c.vTris == bTris->version && c.vVerts == bVerts->version &&
+               c.vObjs == bObjs->version && c.pBVs == bBVs->dev && c.pTris == bTris->dev && c.pVerts == bVerts->dev &&
+               c.pObjs == bObjs->dev && c.sceneStart == sceneStart;
+    };
+    rt_ctx_s::Prep* hit = nullptr;
+    for (auto& c : ctx->preps) if (matches(c)) hit = &c;
+    const bool fresh = hit != nullptr;
     if (!fresh) {
         if (ctx->noAlloc)
             return fail(ctx, RT_ERR_NOT_PREPARED, "the traversal arrays of the bound scene buffers are not built: building them allocates; "
                                                   "dispatch kernel %d once with rt_dispatch after uploading the scene", kernel);
+        // a new entry, or the least recently used one (an entry that failed validation earlier is taken first); its
+        // arrays are reused when they are large enough
+        for (auto& c : ctx->preps) if (!c.valid) hit = &c;
+        if (!hit && ctx->preps.size() < rt_ctx_s::MAX_PREPS) { ctx->preps.emplace_back(); hit = &ctx->preps.back(); }
+        if (!hit) { hit = &ctx->preps[0]; for (auto& c : ctx->preps) if (c.lastUse < hit->lastUse) hit = &c; }
+    }
+    rt_ctx_s::Prep& pr = *hit;
+    pr.lastUse = ++ctx->prepClock;
+    if (!fresh) {
         pr.valid = false;
+        pr.ris = ris;
         HIP_TRY(ctx, hipStreamSynchronize(S(ctx)));
         std::vector<rt_bv> bvs((size_t)bBVs->count);
         std::vector<rt_scene_object> objs((size_t)bObjs->count);
@@ -376,7 +436,7 @@ int prepareScene(rt_shader sh, int kernel, KParams& P, bool ris = false) {
                                (const rt_triangle*)bTris->dev, bTris->count, (const rt_vertex*)bVerts->dev, bVerts->count, pr.btri);
         hipLaunchKernelGGL(k_obj_root_entries, dim3((unsigned)((bObjs->count + 255) / 256)), dim3(256), 0, S(ctx),
                            (const rt_bv*)bBVs->dev, bBVs->count, (const rt_scene_object*)bObjs->dev, bObjs->count, pr.objRoot);
-        HIP_TRY(ctx, hipGetLastError());
+        LAUNCH_TRY(ctx, "build_wide / bake_tris / obj_root_entries");
         // stack entry of the scene root, same rule as the device-side entryOf()
         {
             const rt_bv& r = bvs[sceneStart];
@@ -554,7 +614,7 @@ int pixelGrid(rt_ctx ctx, KParams& P, int gx, int gy, unsigned* blocks, rt_ctx_s
         HIP_TRY(ctx, hipMemsetAsync(m.cost, 0, (size_t)bx * by * 4 * sizeof(uint32_t), S(ctx)));
         m.steps = nullptr; m.stepsValid = false; m.rankedBySteps = false; m.dynHits = nullptr;
         hipLaunchKernelGGL(k_order_blocks, dim3(1), dim3(1024), 0, S(ctx), m.cost, m.bx, m.by, m.dyn, m.nDyn, 0);
-        HIP_TRY(ctx, hipGetLastError());
+        LAUNCH_TRY(ctx, "order_blocks");
         P.blockMap = m.dev;
         *blocks = m.n;
         if (used) *used = &m;
@@ -633,6 +693,7 @@ struct LaunchScope {
         if (start && stop) { hipError_t e = hipEventRecord(start, stream); (void)e; }
     }
     ~LaunchScope() {
+        checkLaunch(ctx, IK_NAMES[ik]);
         if (!start || !stop) return;
         hipError_t e = hipEventRecord(stop, stream);
         (void)e;
@@ -658,6 +719,9 @@ int drainTiming(rt_ctx ctx) {
 void launchHeld(rt_ctx ctx, bool acc) {
     rt_ctx_s::Deferred h = ctx->held;
     ctx->held.kind = 0;   // first: everything below may ask for the stream
+    // the caller may be an entry point that takes no device of its own (rt_stream, the map calls) in a process that
+    // holds contexts on several GPUs
+    { hipError_t e = hipSetDevice(ctx->device); (void)e; }
     if (h.kind == 1) {
         LaunchScope ls(ctx, IK_TRANSFER, &h.P);
         hipLaunchKernelGGL(k_transfer, dim3(h.blocks), dim3(256), 0, ctx->stream0, h.P);
@@ -826,8 +890,7 @@ int dispatchReSTIR(rt_shader sh, int kernel, int gx, int gy) {
         }
         default: return fail(ctx, RT_ERR_INVALID_ARG, "ReSTIR_BVH_RayTracer has no kernel %d", kernel);
     }
-    HIP_TRY(ctx, hipGetLastError());
-    return RT_OK;
+    return finish(ctx);
 }
 
 // RIS_BVH_RayTracer: GenerateCandidates (0), TraceRays (1).  Bindings as BVH_RIS_DL .../ShaderHelper.cs:7-52 and
@@ -915,8 +978,7 @@ int dispatchRIS(rt_shader sh, int kernel, int gx, int gy) {
             else hipLaunchKernelGGL((k_ris_trace_rays<false>), dim3(blocks), dim3(256), ldsBytes, S(ctx), P);
         }
     }
-    HIP_TRY(ctx, hipGetLastError());
-    return RT_OK;
+    return finish(ctx);
 }
 
 int dispatchPreCalc(rt_shader sh, int kernel, int gx) {
@@ -937,9 +999,8 @@ int dispatchPreCalc(rt_shader sh, int kernel, int gx) {
             hipLaunchKernelGGL(k_ris_calc_tri_normals, dim3((unsigned)gx), dim3(256), 0, S(ctx), (rt_ris_tri*)rTris->dev, rTris->count,
                                (const rt_scene_object*)rObjs->dev, rObjs->count, n);
         }
-        HIP_TRY(ctx, hipGetLastError());
         rTris->version = ctx->versionCounter++;
-        return RT_OK;
+        return finish(ctx);
     }
     rt_buffer bTris = boundBuffer(sh, 0, "Triangles"), bVerts = boundBuffer(sh, 0, "Vertices");
     if (!bTris || !bVerts) return fail(ctx, RT_ERR_UNBOUND, "CalcTriNormals needs Triangles and Vertices bound");
@@ -954,9 +1015,8 @@ int dispatchPreCalc(rt_shader sh, int kernel, int gx) {
         hipLaunchKernelGGL(k_calc_tri_normals, dim3((unsigned)gx), dim3(256), 0, S(ctx), (rt_triangle*)bTris->dev, bTris->count,
                            (const rt_vertex*)bVerts->dev, bVerts->count, n);
     }
-    HIP_TRY(ctx, hipGetLastError());
     bTris->version = ctx->versionCounter++;
-    return RT_OK;
+    return finish(ctx);
 }
 
 int dispatchPostProc(rt_shader sh, int kernel, int gx, int gy) {
@@ -986,13 +1046,11 @@ int dispatchPostProc(rt_shader sh, int kernel, int gx, int gy) {
             h.P.accumulated = P.accumulated;
             h.P.ppFrameCount = P.ppFrameCount;
             launchHeld(ctx, true);
-            HIP_TRY(ctx, hipGetLastError());
-            return RT_OK;
+            return finish(ctx);
         }
     }
     if (blocks) { LaunchScope ls(ctx, IK_ACCUMULATE, &P); hipLaunchKernelGGL(k_accumulate, dim3(blocks), dim3(256), 0, S(ctx), P); }
-    HIP_TRY(ctx, hipGetLastError());
-    return RT_OK;
+    return finish(ctx);
 }
 
 }  // namespace
@@ -1013,6 +1071,7 @@ int rt_create(int device_id, rt_ctx* out) {
     static const bool fuse = [] { const char* e = getenv("RT_FUSE"); return e ? atoi(e) != 0 : true; }();
     ctx->fuse = fuse;
     if (hipSetDevice(device_id) != hipSuccess || hipStreamCreateWithFlags(&ctx->stream0, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&ctx->noAllocDone, hipEventDisableTiming) != hipSuccess ||
         hipMalloc((void**)&ctx->statsDev, IK_COUNT * STAT_SHARDS * 8 * sizeof(unsigned long long)) != hipSuccess ||
         hipMemsetAsync(ctx->statsDev, 0, IK_COUNT * STAT_SHARDS * 8 * sizeof(unsigned long long), S(ctx)) != hipSuccess) {
         delete ctx;
@@ -1031,12 +1090,18 @@ void rt_destroy(rt_ctx ctx) {
     if (!ctx) return;
     hipError_t e = hipSetDevice(ctx->device);
     e = hipStreamSynchronize(S(ctx));
-    for (auto& pr : ctx->prep) {
+    {
+        std::lock_guard<std::mutex> lock(scratchMutex);
+        for (auto& o : scratchOwner) if (o == ctx) o = nullptr;
+    }
+    for (auto& pr : ctx->preps) {
         if (pr.wide) e = hipFree(pr.wide);
         if (pr.btri) e = hipFree(pr.btri);
         if (pr.objRoot) e = hipFree(pr.objRoot);
     }
     if (ctx->statsDev) e = hipFree(ctx->statsDev);
+    for (rt_shader sh : ctx->shaders) sh->ctx = nullptr;   // a shader closed after its context only frees itself
+    if (ctx->noAllocDone) e = hipEventDestroy(ctx->noAllocDone);
     for (auto& m : ctx->blockMaps) { e = hipFree(m.dev); if (m.dyn) e = hipFree(m.dyn); if (m.cost) e = hipFree(m.cost); if (m.steps) e = hipFree(m.steps); if (m.dynHits) e = hipFree(m.dynHits); }
     for (auto& t : ctx->pending) { e = hipEventDestroy(t.start); e = hipEventDestroy(t.stop); }
     for (auto ev : ctx->freeEvents) e = hipEventDestroy(ev);
@@ -1052,7 +1117,7 @@ int rt_sync(rt_ctx ctx) {
     if (!ctx) return RT_ERR_INVALID_ARG;
     HIP_TRY(ctx, hipStreamSynchronize(S(ctx)));
     if (ctx->transferStream) HIP_TRY(ctx, hipStreamSynchronize(ctx->transferStream));
-    return RT_OK;
+    return finish(ctx);
 }
 
 void* rt_transfer_stream(rt_ctx ctx) {
@@ -1075,7 +1140,7 @@ int rt_stream_order(rt_ctx ctx, int first) {
     hipStream_t from = first == 0 ? S(ctx) : ctx->transferStream, to = first == 0 ? ctx->transferStream : S(ctx);
     HIP_TRY(ctx, hipEventRecord(ev, from));
     HIP_TRY(ctx, hipStreamWaitEvent(to, ev, 0));
-    return RT_OK;
+    return finish(ctx);
 }
 int rt_mark(rt_ctx ctx, int stream, int slot) {
     if (!ctx || stream < 0 || stream > 1 || slot < 0 || slot >= 64) return RT_ERR_INVALID_ARG;
@@ -1084,7 +1149,7 @@ int rt_mark(rt_ctx ctx, int stream, int slot) {
     if (stream == 1 && !rt_transfer_stream(ctx)) return RT_ERR_NO_DEVICE;
     if (!ctx->marks[slot]) HIP_TRY(ctx, hipEventCreate(&ctx->marks[slot]));
     HIP_TRY(ctx, hipEventRecord(ctx->marks[slot], stream == 0 ? S(ctx) : ctx->transferStream));
-    return RT_OK;
+    return finish(ctx);
 }
 int rt_mark_elapsed(rt_ctx ctx, int a, int b, double* ms) {
     if (!ctx || !ms || a < 0 || a >= 64 || b < 0 || b >= 64) return RT_ERR_INVALID_ARG;
@@ -1096,10 +1161,25 @@ int rt_mark_elapsed(rt_ctx ctx, int a, int b, double* ms) {
     float f = 0;
     HIP_TRY(ctx, hipEventElapsedTime(&f, ctx->marks[a], ctx->marks[b]));
     *ms = f;
-    return RT_OK;
+    return finish(ctx);
 }
 const char* rt_last_error(rt_ctx ctx) { return ctx ? ctx->err.c_str() : "null context"; }
 void* rt_stream(rt_ctx ctx) { return ctx ? (void*)S(ctx) : nullptr; }
+int rt_flush(rt_ctx ctx) {
+    if (!ctx) return RT_ERR_INVALID_ARG;
+    int rc = useDevice(ctx);
+    if (rc) return rc;
+    S(ctx);
+    return finish(ctx);
+}
+int rt_set_fusion(rt_ctx ctx, int enabled) {
+    if (!ctx) return RT_ERR_INVALID_ARG;
+    int rc = useDevice(ctx);
+    if (rc) return rc;
+    S(ctx);
+    ctx->fuse = enabled != 0;
+    return finish(ctx);
+}
 
 int rt_set_row_band(rt_ctx ctx, int row0, int row1) {
     if (!ctx) return RT_ERR_INVALID_ARG;
@@ -1119,10 +1199,18 @@ int rt_shader_open(rt_ctx ctx, const char* name, rt_shader* out) {
     rt_shader sh = new rt_shader_s;
     sh->ctx = ctx;
     sh->kind = kind;
+    ctx->shaders.push_back(sh);
     *out = sh;
     return RT_OK;
 }
-void rt_shader_close(rt_shader sh) { delete sh; }
+void rt_shader_close(rt_shader sh) {
+    if (!sh) return;
+    if (sh->ctx) {
+        auto& v = sh->ctx->shaders;
+        v.erase(std::remove(v.begin(), v.end(), sh), v.end());
+    }
+    delete sh;
+}
 
 int rt_find_kernel(rt_shader sh, const char* name) {
     if (!sh || !name) return RT_ERR_INVALID_ARG;
@@ -1148,7 +1236,7 @@ int rt_dispatch(rt_shader sh, int kernel, int gx, int gy, int gz) {
     if (gx < 0 || gy < 0 || gz < 0) return fail(ctx, RT_ERR_INVALID_ARG, "negative thread-group count");
     int rc = useDevice(ctx);
     if (rc) return rc;
-    if (gx == 0 || gy == 0 || gz == 0) return RT_OK;
+    if (gx == 0 || gy == 0 || gz == 0) return finish(ctx);
     switch (sh->kind) {
         case SH_RESTIR: return dispatchReSTIR(sh, kernel, gx, gy);
         case SH_RIS: return dispatchRIS(sh, kernel, gx, gy);
@@ -1161,9 +1249,20 @@ int rt_dispatch(rt_shader sh, int kernel, int gx, int gy, int gz) {
 int rt_dispatch_no_alloc(rt_shader sh, int kernel, int gx, int gy, int gz) {
     if (!sh) return RT_ERR_INVALID_ARG;
     rt_ctx ctx = sh->ctx;
+    if (!ctx) return RT_ERR_INVALID_ARG;
+    if (ctx->device >= 0 && ctx->device < SCRATCH_MAX_DEVICES) {
+        // every context of this GPU shares one scratch array: refuse the call while another context's launches may
+        // still be reading the table it left there (hipEventQuery allocates nothing)
+        std::lock_guard<std::mutex> lock(scratchMutex);
+        rt_ctx_s*& owner = scratchOwner[ctx->device];
+        if (owner && owner != ctx && hipEventQuery(owner->noAllocDone) == hipErrorNotReady)
+            return fail(ctx, RT_ERR_BUSY, "rt_dispatch_no_alloc: another context's dispatch is still using this GPU's scratch array");
+        owner = ctx;
+    }
     ctx->noAlloc = true;  // every path below that would allocate (or free) device memory returns an error instead
     int rc = rt_dispatch(sh, kernel, gx, gy, gz);
     ctx->noAlloc = false;
+    { hipError_t e = hipEventRecord(ctx->noAllocDone, ctx->stream0); (void)e; }
     return rc;
 }
 
@@ -1230,7 +1329,7 @@ int rt_buffer_create(rt_ctx ctx, int64_t count, int stride, rt_buffer* out) {
         return fail(ctx, e == hipErrorOutOfMemory ? RT_ERR_OUT_OF_MEMORY : RT_ERR_NO_DEVICE, "buffer allocation of %zu bytes failed: %s", (size_t)count * stride, hipGetErrorString(e));
     }
     *out = b;
-    return RT_OK;
+    return finish(ctx);
 }
 
 int rt_buffer_set_data(rt_buffer b, const void* src, size_t bytes) {
@@ -1244,7 +1343,7 @@ int rt_buffer_set_data(rt_buffer b, const void* src, size_t bytes) {
     HIP_TRY(ctx, hipMemcpyAsync(b->dev, src, bytes, hipMemcpyHostToDevice, S(ctx)));
     HIP_TRY(ctx, hipStreamSynchronize(S(ctx)));
     b->version = ctx->versionCounter++;
-    return RT_OK;
+    return finish(ctx);
 }
 
 int rt_buffer_get_data(rt_buffer b, void* dst, size_t bytes) {
@@ -1256,7 +1355,7 @@ int rt_buffer_get_data(rt_buffer b, void* dst, size_t bytes) {
     if (b->layout == LAYOUT_AOS) {
         HIP_TRY(ctx, hipMemcpyAsync(dst, b->dev, bytes, hipMemcpyDeviceToHost, S(ctx)));
         HIP_TRY(ctx, hipStreamSynchronize(S(ctx)));
-        return RT_OK;
+        return finish(ctx);
     }
     void* tmp = nullptr;
     HIP_TRY(ctx, hipMalloc(&tmp, b->bytes));
@@ -1267,7 +1366,7 @@ int rt_buffer_get_data(rt_buffer b, void* dst, size_t bytes) {
     hipError_t e2 = hipFree(tmp);
     (void)e2;
     if (e != hipSuccess) return fail(ctx, RT_ERR_NO_DEVICE, "buffer readback failed: %s", hipGetErrorString(e));
-    return RT_OK;
+    return finish(ctx);
 }
 
 int rt_buffer_get_range(rt_buffer b, void* dst, int64_t first, int64_t count) {
@@ -1275,14 +1374,14 @@ int rt_buffer_get_range(rt_buffer b, void* dst, int64_t first, int64_t count) {
     rt_ctx ctx = b->ctx;
     if (first < 0 || count < 0 || first + count > b->count)
         return fail(ctx, RT_ERR_INVALID_ARG, "elements [%lld, %lld) are outside a buffer of %lld", (long long)first, (long long)(first + count), (long long)b->count);
-    if (count == 0) return RT_OK;
+    if (count == 0) return finish(ctx);
     int rc = useDevice(ctx);
     if (rc) return rc;
     const size_t bytes = (size_t)count * b->stride;
     if (b->layout == LAYOUT_AOS) {
         HIP_TRY(ctx, hipMemcpyAsync(dst, (const char*)b->dev + (size_t)first * b->stride, bytes, hipMemcpyDeviceToHost, S(ctx)));
         HIP_TRY(ctx, hipStreamSynchronize(S(ctx)));
-        return RT_OK;
+        return finish(ctx);
     }
     void* tmp = nullptr;
     HIP_TRY(ctx, hipMalloc(&tmp, bytes));
@@ -1293,13 +1392,28 @@ int rt_buffer_get_range(rt_buffer b, void* dst, int64_t first, int64_t count) {
     hipError_t e2 = hipFree(tmp);
     (void)e2;
     if (e != hipSuccess) return fail(ctx, RT_ERR_NO_DEVICE, "buffer readback failed: %s", hipGetErrorString(e));
-    return RT_OK;
+    return finish(ctx);
 }
 
+// Unity's Release leaves the ComputeBuffer object unusable; a shader that still has it bound fails its next dispatch.
+// Here the handle is taken out of every binding table of the context's shaders, so that such a dispatch fails with
+// RT_ERR_UNBOUND instead of reading freed memory, and the traversal arrays derived from a scene buffer go with it.
 void rt_buffer_release(rt_buffer b) {
     if (!b) return;
-    hipError_t e = hipSetDevice(b->ctx->device);
-    e = hipStreamSynchronize(S(b->ctx));
+    rt_ctx ctx = b->ctx;
+    hipError_t e = hipSetDevice(ctx->device);
+    e = hipStreamSynchronize(S(ctx));   // launches what is held first: it may read this buffer
+    if (ctx->transferStream) e = hipStreamSynchronize(ctx->transferStream);
+    for (rt_shader sh : ctx->shaders)
+        for (auto& table : sh->buffers)
+            for (auto it = table.begin(); it != table.end();) it = it->second == b ? table.erase(it) : std::next(it);
+    for (auto& pr : ctx->preps) {
+        if (pr.pBVs != b->dev && pr.pTris != b->dev && pr.pVerts != b->dev && pr.pObjs != b->dev) continue;
+        if (pr.wide) e = hipFree(pr.wide);
+        if (pr.btri) e = hipFree(pr.btri);
+        if (pr.objRoot) e = hipFree(pr.objRoot);
+        pr = rt_ctx_s::Prep();
+    }
     if (b->dev) e = hipFree(b->dev);
     (void)e;
     delete b;
@@ -1327,7 +1441,7 @@ int rt_texture_create(rt_ctx ctx, int w, int h, rt_format format, rt_texture* ou
         return fail(ctx, e == hipErrorOutOfMemory ? RT_ERR_OUT_OF_MEMORY : RT_ERR_NO_DEVICE, "texture allocation failed: %s", hipGetErrorString(e));
     }
     *out = t;
-    return RT_OK;
+    return finish(ctx);
 }
 
 int rt_texture_set_data(rt_texture t, const void* src, size_t bytes) {
@@ -1349,13 +1463,13 @@ int rt_texture_set_data(rt_texture t, const void* src, size_t bytes) {
         hipError_t e2 = hipFree(tmp);
         (void)e2;
         if (e != hipSuccess) return fail(ctx, RT_ERR_NO_DEVICE, "texture upload failed: %s", hipGetErrorString(e));
-        return RT_OK;
+        return finish(ctx);
     }
     if (bytes != t->bytes) return fail(ctx, RT_ERR_INVALID_ARG, "texture upload must be %zu bytes", t->bytes);
     HIP_TRY(ctx, hipMemcpyAsync(t->dev, src, bytes, hipMemcpyHostToDevice, S(ctx)));
     HIP_TRY(ctx, hipStreamSynchronize(S(ctx)));
     t->version = ctx->versionCounter++;
-    return RT_OK;
+    return finish(ctx);
 }
 
 int rt_texture_get_data(rt_texture t, void* dst, size_t bytes) {
@@ -1366,26 +1480,31 @@ int rt_texture_get_data(rt_texture t, void* dst, size_t bytes) {
     if (rc) return rc;
     HIP_TRY(ctx, hipMemcpyAsync(dst, t->dev, bytes, hipMemcpyDeviceToHost, S(ctx)));
     HIP_TRY(ctx, hipStreamSynchronize(S(ctx)));
-    return RT_OK;
+    return finish(ctx);
 }
 
 int rt_texture_get_rows(rt_texture t, void* dst, int row0, int row1) {
     if (!t || !dst) return RT_ERR_INVALID_ARG;
     rt_ctx ctx = t->ctx;
     if (row0 < 0 || row1 < row0 || row1 > t->h) return fail(ctx, RT_ERR_INVALID_ARG, "rows [%d,%d) are outside the texture", row0, row1);
-    if (row1 == row0) return RT_OK;
+    if (row1 == row0) return finish(ctx);
     int rc = useDevice(ctx);
     if (rc) return rc;
     const size_t rowBytes = (size_t)t->w * (t->format == RT_FORMAT_R32F ? 4 : 16);
     HIP_TRY(ctx, hipMemcpyAsync(dst, (const char*)t->dev + rowBytes * row0, rowBytes * (size_t)(row1 - row0), hipMemcpyDeviceToHost, S(ctx)));
     HIP_TRY(ctx, hipStreamSynchronize(S(ctx)));
-    return RT_OK;
+    return finish(ctx);
 }
 
 void rt_texture_release(rt_texture t) {
     if (!t) return;
-    hipError_t e = hipSetDevice(t->ctx->device);
-    e = hipStreamSynchronize(S(t->ctx));
+    rt_ctx ctx = t->ctx;
+    hipError_t e = hipSetDevice(ctx->device);
+    e = hipStreamSynchronize(S(ctx));
+    if (ctx->transferStream) e = hipStreamSynchronize(ctx->transferStream);
+    for (rt_shader sh : ctx->shaders)   // as rt_buffer_release: no binding may keep the handle
+        for (auto& table : sh->textures)
+            for (auto it = table.begin(); it != table.end();) it = it->second == t ? table.erase(it) : std::next(it);
     if (t->dev) e = hipFree(t->dev);
     (void)e;
     delete t;
@@ -1410,7 +1529,7 @@ int rt_buffer_map_rows(rt_buffer b, int width, int row0, int row1, rt_segment ou
         out[3].ptr = base + (size_t)b->count * 48 + first * 4; out[3].bytes = n * 4;
         *count = 4;
     }
-    return RT_OK;
+    return finish(ctx);
 }
 int rt_texture_map_rows(rt_texture t, int row0, int row1, rt_segment* out) {
     if (!t || !out) return RT_ERR_INVALID_ARG;
@@ -1419,7 +1538,7 @@ int rt_texture_map_rows(rt_texture t, int row0, int row1, rt_segment* out) {
     const size_t texel = t->format == RT_FORMAT_R32F ? 4 : 16;
     out->ptr = (char*)t->dev + (size_t)row0 * t->w * texel;
     out->bytes = (size_t)(row1 - row0) * t->w * texel;
-    return RT_OK;
+    return finish(t->ctx);
 }
 
 int rt_enable_stats(rt_ctx ctx, int level) {
@@ -1429,7 +1548,7 @@ int rt_enable_stats(rt_ctx ctx, int level) {
     if (level != ctx->statsLevel)  // counters restart whenever the level changes
         HIP_TRY(ctx, hipMemsetAsync(ctx->statsDev, 0, IK_COUNT * STAT_SHARDS * 8 * sizeof(unsigned long long), S(ctx)));
     ctx->statsLevel = level;
-    return RT_OK;
+    return finish(ctx);
 }
 static int fetchStats(rt_ctx ctx, int ik, bool reset, unsigned long long h[8]) {
     unsigned long long raw[STAT_SHARDS * 8];
@@ -1438,7 +1557,7 @@ static int fetchStats(rt_ctx ctx, int ik, bool reset, unsigned long long h[8]) {
     if (reset) HIP_TRY(ctx, hipMemsetAsync(src, 0, sizeof raw, S(ctx)));
     HIP_TRY(ctx, hipStreamSynchronize(S(ctx)));
     for (int c = 0; c < 8; c++) { h[c] = 0; for (int s = 0; s < STAT_SHARDS; s++) h[c] += raw[s * 8 + c]; }
-    return RT_OK;
+    return finish(ctx);
 }
 static int readStats(rt_ctx ctx, int ik, rt_dispatch_stats* acc) {
     unsigned long long h[8];
@@ -1447,7 +1566,7 @@ static int readStats(rt_ctx ctx, int ik, rt_dispatch_stats* acc) {
     acc->rays += h[ST_RAYS]; acc->pops += h[ST_POPS]; acc->bvChecks += h[ST_BVCHECKS]; acc->objVisits += h[ST_OBJVISITS];
     acc->triIters += h[ST_TRIITERS]; acc->triChecks += h[ST_TRICHECKS]; acc->validNeighbours += h[ST_NEIGHBOURS];
     acc->activePixels += h[ST_ACTIVE];
-    return RT_OK;
+    return finish(ctx);
 }
 int rt_get_stats(rt_shader sh, int kernel, rt_dispatch_stats* out) {
     if (!sh || !out || kernel < 0 || kernel >= 8) return RT_ERR_INVALID_ARG;
@@ -1460,7 +1579,7 @@ int rt_get_stats(rt_shader sh, int kernel, rt_dispatch_stats* out) {
         if (kernel >= 5) return fail(ctx, RT_ERR_INVALID_ARG, "no kernel %d", kernel);
         for (int j = 0; j < 2; j++)
             if (map[kernel][j] >= 0 && (rc = readStats(ctx, map[kernel][j], out))) return rc;
-        return RT_OK;
+        return finish(ctx);
     }
     if (sh->kind == SH_RIS) {
         if (kernel == 0) { if ((rc = readStats(ctx, IK_RIS_PRIMARY, out))) return rc; return readStats(ctx, IK_RIS_CANDIDATES, out); }
@@ -1477,7 +1596,7 @@ int rt_profile_enable(rt_ctx ctx, int timing) {
     if (rc) return rc;
     if ((rc = drainTiming(ctx))) return rc;
     ctx->timing = timing != 0;
-    return RT_OK;
+    return finish(ctx);
 }
 int rt_profile_select(rt_ctx ctx, const char* kernel_name) {
     if (!ctx) return RT_ERR_INVALID_ARG;
@@ -1487,7 +1606,7 @@ int rt_profile_select(rt_ctx ctx, const char* kernel_name) {
         if (ik < 0) return fail(ctx, RT_ERR_INVALID_ARG, "unknown kernel name '%s'", kernel_name);
     }
     ctx->timingOnly = ik;
-    return RT_OK;
+    return finish(ctx);
 }
 int rt_profile_reset(rt_ctx ctx) {
     if (!ctx) return RT_ERR_INVALID_ARG;
@@ -1497,7 +1616,7 @@ int rt_profile_reset(rt_ctx ctx) {
     for (int i = 0; i < IK_COUNT; i++) { ctx->timeMs[i] = 0; ctx->launches[i] = 0; }
     HIP_TRY(ctx, hipMemsetAsync(ctx->statsDev, 0, IK_COUNT * STAT_SHARDS * 8 * sizeof(unsigned long long), S(ctx)));
     HIP_TRY(ctx, hipStreamSynchronize(S(ctx)));
-    return RT_OK;
+    return finish(ctx);
 }
 int rt_profile_get(rt_ctx ctx, const char* kernel_name, rt_kernel_profile* out) {
     if (!ctx || !kernel_name || !out) return RT_ERR_INVALID_ARG;
@@ -1515,7 +1634,7 @@ int rt_profile_get(rt_ctx ctx, const char* kernel_name, rt_kernel_profile* out) 
     out->stats.rays = h[ST_RAYS]; out->stats.pops = h[ST_POPS]; out->stats.bvChecks = h[ST_BVCHECKS];
     out->stats.objVisits = h[ST_OBJVISITS]; out->stats.triIters = h[ST_TRIITERS]; out->stats.triChecks = h[ST_TRICHECKS];
     out->stats.validNeighbours = h[ST_NEIGHBOURS]; out->stats.activePixels = h[ST_ACTIVE];
-    return RT_OK;
+    return finish(ctx);
 }
 
 }  // extern "C"

@@ -22,8 +22,10 @@ using namespace shim;
 struct rth_main_s {
     rt_ctx ctx = nullptr;
     rth_main_config cfg;
+    rth_scene sceneHandle = nullptr;   // ObjectHelper: SetData asks it for the scene arrays again on every reload
     rth_scene_data scene;
     std::string err;
+    bool DoUpdateSettings = false, DoReloadData = false;   // Main.cs:84-85
 
     ComputeShader rtShader, ppShader, pcShader;
     int FrameCount = 0;
@@ -72,6 +74,15 @@ struct rth_main_s {
     void SetTemporalFrameBuffer() { rtShader.SetBuffer(3, "TemporalFrameBuffer", TemporalFrameBuffer); rtShader.SetBuffer(4, "TemporalFrameBuffer", TemporalFrameBuffer); }
     void SetHitInfoBuffer() { rtShader.SetBuffer(0, "HitInfos", HitInfoBuffer); rtShader.SetBuffer(4, "HitInfos", HitInfoBuffer); }
 
+    // Main.cs:117-132 (without the pause controls): the per-frame constants, then - when an inspector value changed
+    // or a scene object moved since the last frame (OnValidate :206-209, SceneObjectSettings.cs:18-36) - every setting
+    // again and, with them, the scene data.  UpdateSettings runs AFTER UpdatePerFrame: the frame that reloads is
+    // rendered with the FrameCount already pushed, on freshly zeroed per-pixel buffers, and the count restarts at 0
+    // with the frame after it (:213).
+    void Update() {
+        UpdatePerFrame();
+        if (DoUpdateSettings) { DoUpdateSettings = false; UpdateSettings(DoReloadData); DoReloadData = false; }
+    }
     // Main.cs:134-145
     void UpdatePerFrame() {
         int FrameRand = (int)(((uint64_t)cfg.frameRandBase + (uint64_t)cfg.frameRandStep * (uint64_t)framesStarted) % 999999u);
@@ -138,6 +149,9 @@ struct rth_main_s {
     }
     // Main.cs:273-310 (+ ObjectHelper.ConstructScene's SetInt/SetFloat calls, ObjectHelper.cs:637,647,686,696)
     void SetData() {
+        ReleaseBuffers();  // ComputeHelper.Release(AllBuffers()), Main.cs:275
+        // objectHelper.ConstructScene() (:278): the arrays as the scene holds them now
+        if (rth_scene_get(sceneHandle, &scene) != 0) throw DriverError{"the scene is not built"};
         rtShader.SetInt("MaxBVHDepth", scene.maxBVHDepth);
         rtShader.SetFloat("TotArea", scene.totArea);
         rtShader.SetInt("SceneBVHStartIndex", scene.sceneBVHStartIndex);
@@ -251,10 +265,13 @@ struct rth_main_s {
         SetCameraData();
         framesStarted = 0;  // FrameRand numbering starts with the first rendered frame
     }
-    void ReleaseAll() {  // Main.cs:507-513
+    void ReleaseBuffers() {  // AllBuffers(), Main.cs:507
         ComputeBuffer* bufs[] = {&BVBuffer, &RenderTriangleBuffer, &VertexBuffer, &SceneObjectDataBuffer, &LightObjectBuffer, &MaterialBuffer,
                                  &CandidateBuffer, &CandidateReuseBuffer, &TemporalFrameBuffer, &HitInfoBuffer};
         for (auto* b : bufs) b->Release();
+    }
+    void ReleaseAll() {  // Main.cs:509-513
+        ReleaseBuffers();
         RenderTexture* texs[] = {&RTResultTexture, &AccumulatedResultTexture, &DebugOverlayTexture, &RayHitPointATexture, &RayHitPointBTexture,
                                  &DepthBufferTexture, &NormalsBufferTexture, &TextureAtlas, &EnvironmentMapTexture};
         for (auto* t : texs) t->Release();
@@ -320,6 +337,7 @@ rth_main rth_main_create(rt_ctx ctx, const rth_main_config* cfg, rth_scene scene
     rth_main m = new rth_main_s;
     m->ctx = ctx;
     m->cfg = *cfg;
+    m->sceneHandle = scene;
     if (rth_scene_get(scene, &m->scene) != 0) { delete m; return nullptr; }
     if (cfg->Resolution[0] < 1 || cfg->Resolution[1] < 1) { delete m; return nullptr; }
     int rc = guarded(m, [&] {
@@ -345,7 +363,22 @@ void rth_main_destroy(rth_main m) {
 }
 const char* rth_main_last_error(rth_main m) { return m ? m->err.c_str() : "null driver"; }
 
-int rth_main_update_per_frame(rth_main m) { return guarded(m, [&] { m->UpdatePerFrame(); }); }
+int rth_main_update_per_frame(rth_main m) { return guarded(m, [&] { m->Update(); }); }
+int rth_main_reload(rth_main m, const rth_main_config* cfg) {
+    if (!m) return -1;
+    if (cfg) {
+        // the render targets are created once, at the size of the first frame (CreateTextures, Main.cs:312-380)
+        if (cfg->Resolution[0] != m->cfg.Resolution[0] || cfg->Resolution[1] != m->cfg.Resolution[1] ||
+            cfg->Unorm8RenderTargets != m->cfg.Unorm8RenderTargets) {
+            m->err = "Resolution and the render-target format cannot change on a reload";
+            return -1;
+        }
+        m->cfg = *cfg;
+    }
+    m->DoUpdateSettings = true;
+    m->DoReloadData = true;
+    return 0;
+}
 int rth_main_run_restir_shader(rth_main m) { return guarded(m, [&] { m->RunReSTIRShader(); }); }
 int rth_main_run_post_processing(rth_main m) { return guarded(m, [&] { m->RunPostProcessingShader(); }); }
 int rth_main_run_stage(rth_main m, int stage) { return guarded(m, [&] { m->RunStage(stage); }); }
@@ -353,7 +386,7 @@ int rth_main_run_spatial_pass(rth_main m, int i) { return guarded(m, [&] { m->Cr
 int rth_main_run_transfer(rth_main m) { return guarded(m, [&] { m->CreateTextures(); m->TransferIfNeeded(); }); }
 int rth_main_render_frame(rth_main m) {
     return guarded(m, [&] {
-        m->UpdatePerFrame();
+        m->Update();
         m->RunReSTIRShader();
         m->RunPostProcessingShader();
     });
@@ -718,7 +751,7 @@ void mgPhase(rth_mg g, int phase) {
     switch (phase) {
         case 0:
             rows(b0, b1);
-            m->UpdatePerFrame();
+            m->Update();
             m->RunStage(0);
             m->RunStage(1);
             return;

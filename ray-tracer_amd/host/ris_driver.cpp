@@ -20,7 +20,9 @@ using namespace shim;
 struct rth_ris_main_s {
     rt_ctx ctx = nullptr;
     rth_ris_config cfg;
+    rth_scene sceneHandle = nullptr;
     rth_scene_data scene;
+    bool DoUpdateSettings = false;   // Main.cs:48
     std::vector<rt_ris_tri> Tris;
     std::vector<rt_ris_material> Material2s;
     std::string err;
@@ -88,6 +90,11 @@ struct rth_ris_main_s {
     void SetCandidateBuffer() { rtShader.SetBuffer(0, "Candidates", CandidateBuffer); rtShader.SetBuffer(1, "Candidates", CandidateBuffer); }
     void SetHitInfoBuffer() { rtShader.SetBuffer(0, "HitInfos", HitInfoBuffer); rtShader.SetBuffer(1, "HitInfos", HitInfoBuffer); }
 
+    // Main.cs:105-120 (without the pause controls)
+    void Update() {
+        UpdatePerFrame();
+        if (DoUpdateSettings) { DoUpdateSettings = false; UpdateSettings(); }
+    }
     // Main.cs:132-144
     void UpdatePerFrame() {
         int FrameRand = (int)(((uint64_t)cfg.frameRandBase + (uint64_t)cfg.frameRandStep * (uint64_t)framesStarted) % 999999u);
@@ -133,6 +140,10 @@ struct rth_ris_main_s {
     }
     // Main.cs:267-312 (+ MeshHelper.CreateSceneObjects' SetInt/SetFloat calls, MeshHelper.cs:365,395,403,422)
     void SetData() {
+        ReleaseBuffers();  // ComputeHelper.Release(AllBuffers()), Main.cs:269
+        // meshHelper.CreateSceneObjects() (:287): the arrays as the scene holds them now
+        if (rth_scene_get(sceneHandle, &scene) != 0) throw DriverError{"the scene is not built"};
+        BuildRisArrays();
         if (!testTexture.h) testTexture = CreateTexture(ctx, {1, 1}, RT_FORMAT_RGBA8_UNORM);
         MaterialBuffer = ComputeHelper::CreateStructuredBuffer(ctx, Material2s.data(), (int64_t)Material2s.size(), sizeof(rt_ris_material));
         SetMaterialBuffer();
@@ -186,9 +197,12 @@ struct rth_ris_main_s {
         UpdateSettings();
         framesStarted = 0;  // FrameRand numbering starts with the first rendered frame
     }
-    void ReleaseAll() {
+    void ReleaseBuffers() {  // AllBuffers(), Main.cs:389
         ComputeBuffer* bufs[] = {&BVBuffer, &TriBuffer, &SceneObjectDataBuffer, &LightObjectBuffer, &MaterialBuffer, &CandidateBuffer, &HitInfoBuffer};
         for (auto* b : bufs) b->Release();
+    }
+    void ReleaseAll() {
+        ReleaseBuffers();
         RenderTexture* texs[] = {&RTResultTexture, &AccumulatedResultTexture, &DebugOverlayTexture, &RayHitPointTexture, &testTexture};
         for (auto* t : texs) t->Release();
         rt_shader_close(rtShader.h); rt_shader_close(ppShader.h); rt_shader_close(pcShader.h);
@@ -256,10 +270,10 @@ rth_ris_main rth_ris_main_create(rt_ctx ctx, const rth_ris_config* cfg, rth_scen
     rth_ris_main m = new rth_ris_main_s;
     m->ctx = ctx;
     m->cfg = *cfg;
+    m->sceneHandle = scene;
     if (rth_scene_get(scene, &m->scene) != 0) { delete m; return nullptr; }
     int rc = guarded(m, [&] {
         m->rtShader.ctx = m->ppShader.ctx = m->pcShader.ctx = ctx;
-        m->BuildRisArrays();
         if (rt_set_row_band(ctx, row0, row1) < 0) throw DriverError{rt_last_error(ctx)};
         if (rt_shader_open(ctx, "RIS_BVH_RayTracer", &m->rtShader.h) < 0) throw DriverError{rt_last_error(ctx)};
         if (rt_shader_open(ctx, "PostProcesser", &m->ppShader.h) < 0) throw DriverError{rt_last_error(ctx)};
@@ -281,12 +295,17 @@ void rth_ris_main_destroy(rth_ris_main m) {
 }
 const char* rth_ris_main_last_error(rth_ris_main m) { return m ? m->err.c_str() : "null driver"; }
 
-int rth_ris_main_update_per_frame(rth_ris_main m) { return guarded(m, [&] { m->UpdatePerFrame(); }); }
+int rth_ris_main_update_per_frame(rth_ris_main m) { return guarded(m, [&] { m->Update(); }); }
+int rth_ris_main_reload(rth_ris_main m) {
+    if (!m) return -1;
+    m->DoUpdateSettings = true;
+    return 0;
+}
 int rth_ris_main_run_stage(rth_ris_main m, int stage) { return guarded(m, [&] { m->RunStage(stage); }); }
 int rth_ris_main_run_post_processing(rth_ris_main m) { return guarded(m, [&] { m->CreateTextures(); m->RunPostProcessingShader(); }); }
 int rth_ris_main_render_frame(rth_ris_main m) {
     return guarded(m, [&] {
-        m->UpdatePerFrame();
+        m->Update();
         m->RunRenderShader();
         m->RunPostProcessingShader();
     });

@@ -79,6 +79,17 @@ int rth_scene_add_object(rth_scene s, int meshId, const float position[3], const
                          const float scale[3], int materialIndex, int maxDepthBVH);
 /* ObjectHelper.ConstructScene (ObjectHelper.cs:666-738) on the registered objects.  threads <= 0: all cores. */
 int rth_scene_build(rth_scene s, int threads);
+/* transform.position / rotation / localScale of object `objectIndex` (the value rth_scene_add_object returned) change.
+ * In the reference that makes SceneObjectSettings.LateUpdate request a reload (SceneObjectSettings.cs:27-36). */
+int rth_scene_set_object_transform(rth_scene s, int objectIndex, const float position[3], const float eulerDeg[3], const float scale[3]);
+/* ConstructScene called again on a built scene (what Main.SetData does on a reload, Main.cs:278): meshes already loaded
+ * keep their BVHs, vertices and triangles (ObjectHelper.cs:582-594); the per-object matrices and boxes, the scene BVH
+ * and the light list are made anew.  keepOldSceneBVH = 1 is the ReSTIR project's behaviour: the new scene BVH is
+ * appended behind the old one, which stays in BVs unreferenced (LastSceneBVHLength is never set, ObjectHelper.cs:38,
+ * 613-614), so BVsNum grows and SceneBVHStartIndex moves up with every reload; 0 is the RIS project's, which drops the
+ * old scene BVH first (BVH_RIS_DL/Assets/Scripts/MeshHelper.cs:371-372,418).  Pointers obtained from rth_scene_get are
+ * invalidated. */
+int rth_scene_rebuild(rth_scene s, int keepOldSceneBVH);
 
 typedef struct {
     const rt_bv* BVs; int64_t nBVs;
@@ -147,10 +158,19 @@ rth_main rth_main_create(rt_ctx ctx, const rth_main_config* cfg, rth_scene scene
 void rth_main_destroy(rth_main m);
 const char* rth_main_last_error(rth_main m);
 
-/* One Unity frame: Update -> UpdatePerFrame (Main.cs:134-145), then OnRenderImage -> RunReSTIRShader (:404-415)
- * and RunPostProcessingShader (:417-420).  Asynchronous; returns after enqueueing. */
+/* One Unity frame: Update (Main.cs:117-132: UpdatePerFrame :134-145, then UpdateSettings if a reload was requested),
+ * then OnRenderImage -> RunReSTIRShader (:404-415) and RunPostProcessingShader (:417-420).  Asynchronous; returns
+ * after enqueueing. */
 int rth_main_render_frame(rth_main m);
-/* The two halves separately, for tests that interleave readbacks: */
+/* Requests what OnValidate / SceneObjectSettings.LateUpdate request (Main.cs:206-209, SceneObjectSettings.cs:27-36):
+ * DoUpdateSettings and DoReloadData.  The NEXT Update then runs UpdateSettings(true) after its UpdatePerFrame
+ * (Main.cs:127-129): FrameCount restarts at 0 from the frame after, SetData releases all ten buffers, takes the scene
+ * arrays from the scene again (call rth_scene_rebuild first if objects moved), uploads them, runs CalcTriNormals and
+ * creates the four per-pixel buffers anew (zeroed), and every setting is pushed again.  The render targets stay as
+ * they are.  cfg: new inspector values, or NULL to keep them (Resolution and Unorm8RenderTargets may not change). */
+int rth_main_reload(rth_main m, const rth_main_config* cfg);
+/* The two halves separately, for tests that interleave readbacks (rth_main_update_per_frame is Update: it performs
+ * a requested reload): */
 int rth_main_update_per_frame(rth_main m);
 int rth_main_run_restir_shader(rth_main m);
 int rth_main_run_post_processing(rth_main m);
@@ -260,7 +280,11 @@ void rth_ris_main_destroy(rth_ris_main m);
 const char* rth_ris_main_last_error(rth_ris_main m);
 /* One frame: UpdatePerFrame (:132-144), RunRenderShader (:319-371), RunPostProcessingShader (:373-376). */
 int rth_ris_main_render_frame(rth_ris_main m);
-int rth_ris_main_update_per_frame(rth_ris_main m);
+int rth_ris_main_update_per_frame(rth_ris_main m);   /* Update: performs a requested reload after UpdatePerFrame */
+/* DoUpdateSettings (BVH_RIS_DL Main.cs:117,126,218; SceneObjectSettings.cs:26,32; any camera or object move sets it):
+ * the next Update runs UpdateSettings -> SetData after its UpdatePerFrame: FrameCount restarts, all seven buffers are
+ * released and created again from the scene as it is now, CalcTriNormals runs again. */
+int rth_ris_main_reload(rth_ris_main m);
 int rth_ris_main_run_stage(rth_ris_main m, int stage); /* 0 GenerateCandidates, 1 TraceRays */
 int rth_ris_main_run_post_processing(rth_ris_main m);
 int rth_ris_main_frame_count(rth_ris_main m);

@@ -359,6 +359,7 @@ struct rth_scene_s {
     std::vector<unsigned char> atlas;
     int atlasW = 1, atlasH = 1;
     std::vector<ObjectDesc> objects;
+    std::vector<LoadedMesh> loaded;  // LoadedMeshes (ObjectHelper.cs:30): the meshes whose BVH is part of BVs, by mesh id
     // outputs
     std::vector<rt_bv> BVs;
     std::vector<rt_int2> componentDatas;
@@ -368,148 +369,21 @@ struct rth_scene_s {
     std::vector<rt_light_object> lightObjects;
     std::vector<rt_material> materials;
     int maxBVHDepth = 0, emittingObjectsNum = 0, sceneBVHStartIndex = 0;
+    int lastSceneBVHLength = 0;  // nodes of the scene BVH at the end of BVs
     float totArea = 0;
     bool built = false;
 };
 
-extern "C" {
+namespace {
 
-rth_scene rth_scene_create(int splitResolution, int maxDepthSceneBVH) {
-    if (splitResolution < 1) return nullptr;
-    rth_scene s = new rth_scene_s;
-    s->splitResolution = splitResolution;
-    s->maxDepthSceneBVH = maxDepthSceneBVH;
-    return s;
-}
-void rth_scene_free(rth_scene s) { delete s; }
-int rth_scene_add_material(rth_scene s, const rth_material_input* m) {
-    if (!s || !m) return -1;
-    s->materialInputs.push_back(*m);
-    s->materialTextures.emplace_back();
-    return (int)s->materialInputs.size() - 1;
-}
-int rth_scene_add_material_textured(rth_scene s, const rth_material_input* m, const rth_texture_input tex[5]) {
-    if (!s || !m || !tex) return -1;
-    std::array<rth_scene_s::Tex, 5> t;
-    for (int k = 0; k < 5; k++) {
-        if (!tex[k].pixels) continue;
-        if (tex[k].width < 1 || tex[k].height < 1 || tex[k].width > 8192 || tex[k].height > 8192) return -1;
-        t[(size_t)k].w = tex[k].width; t[(size_t)k].h = tex[k].height;
-        t[(size_t)k].px.assign(tex[k].pixels, tex[k].pixels + (size_t)tex[k].width * tex[k].height * 4);
-    }
-    s->materialInputs.push_back(*m);
-    s->materialTextures.push_back(std::move(t));
-    return (int)s->materialInputs.size() - 1;
-}
-int rth_scene_add_mesh(rth_scene s, rth_mesh m) {
-    if (!s || !m) return -1;
-    s->meshes.push_back(*m);
-    return (int)s->meshes.size() - 1;
-}
-int rth_scene_add_object(rth_scene s, int meshId, const float position[3], const float eulerDeg[3], const float scale[3],
-                         int materialIndex, int maxDepthBVH) {
-    if (!s || meshId < 0 || meshId >= (int)s->meshes.size() || materialIndex < 0 ||
-        materialIndex >= (int)s->materialInputs.size())
-        return -1;
-    ObjectDesc o;
-    o.meshId = meshId;
-    memcpy(o.pos, position, 12);
-    memcpy(o.rot, eulerDeg, 12);
-    memcpy(o.scale, scale, 12);
-    o.materialIndex = materialIndex;
-    o.maxDepthBVH = maxDepthBVH;
-    s->objects.push_back(o);
-    return (int)s->objects.size() - 1;
-}
-
-void rth_world_to_local(const float position[3], const float eulerDeg[3], const float scale[3], float outW2L[16],
-                        float outL2W[16]) {
-    M4 w2l = createWorldToLocal(position, eulerDeg, scale);
-    M4 l2w = inverse(w2l);
-    memcpy(outW2L, w2l.m, 64);
-    memcpy(outL2W, l2w.m, 64);
-}
-
-int rth_scene_build(rth_scene s, int threads) {
-    if (!s || s->objects.empty()) return -1;
-    if (threads <= 0) threads = omp_get_max_threads();
+// The part of ConstructScene that runs on every call (ObjectHelper.cs:684-712): LoadSceneObjects' per-object data
+// (:561-602, the mesh BVHs themselves are looked up by mesh key and kept), ConstructSceneBVH (:609-664) and the light
+// list (:694-712).  The scene BVH is APPENDED to BVs / componentDatas: the reference means to drop the previous one
+// first (:613-614) but never records its length (LastSceneBVHLength stays 0, :38), so after a reload the old scene
+// nodes stay in the buffer, unreferenced, and SceneBVHStartIndex moves up past them.
+void constructSceneLevel(rth_scene s) {
     const int nObj = (int)s->objects.size();
-    const int nMesh = (int)s->meshes.size();
-
-    if (!rth_scene_make_materials(s)) return -1;
-
-    // ---- LoadSceneObjects (:556-607): meshes get their BVH the first time an object uses them ----
-    std::vector<int> firstUseOrder;          // mesh ids in order of first use
-    std::vector<int> meshMaxDepth(nMesh, 0); // the depth of the first object that uses the mesh
-    std::vector<char> used(nMesh, 0);
-    for (const auto& o : s->objects)
-        if (!used[o.meshId]) { used[o.meshId] = 1; firstUseOrder.push_back(o.meshId); meshMaxDepth[o.meshId] = o.maxDepthBVH; }
-
-    struct MeshBuild { std::vector<BVNode> nodes; std::vector<Comp> comps; std::vector<float> area; };
-    std::vector<MeshBuild> builds(nMesh);
-    const int nUse = (int)firstUseOrder.size();
-#pragma omp parallel for schedule(dynamic, 1) num_threads(threads)
-    for (int u = 0; u < nUse; u++) {
-        int id = firstUseOrder[u];
-        const rth_mesh_s& mesh = s->meshes[id];
-        MeshBuild& mb = builds[id];
-        size_t nt = mesh.tris.size() / 3;
-        mb.comps.resize(nt);
-        mb.area.resize(nt);
-        for (size_t t = 0; t < nt; t++) {  // Triangle.Initialise (Triangle.cs:17-46)
-            V3 v0 = toV3(mesh.verts[mesh.tris[3 * t]].pos), v1 = toV3(mesh.verts[mesh.tris[3 * t + 1]].pos),
-               v2 = toV3(mesh.verts[mesh.tris[3 * t + 2]].pos);
-            mb.comps[t].mn = vmin(vmin(v0, v1), v2);
-            mb.comps[t].mx = vmax(vmax(v0, v1), v2);
-            mb.comps[t].payload = (int32_t)t;
-            V3 ab = {v1.x - v0.x, v1.y - v0.y, v1.z - v0.z}, ac = {v2.x - v0.x, v2.y - v0.y, v2.z - v0.z};
-            V3 cr = {ab.y * ac.z - ab.z * ac.y, ab.z * ac.x - ab.x * ac.z, ab.x * ac.y - ab.y * ac.x};
-            mb.area[t] = sqrtf(cr.x * cr.x + cr.y * cr.y + cr.z * cr.z) * 0.5f;  // Func.GetTriArea (Resources.cs:294-301)
-        }
-        Builder b;
-        b.splitResolution = s->splitResolution;
-        b.build(mb.comps, meshMaxDepth[id]);
-        mb.nodes.swap(b.nodes);
-    }
-
-    // ---- concatenate in first-use order: ConstructBVH (:303-347) ----
-    s->BVs.clear(); s->componentDatas.clear(); s->vertices.clear(); s->triangles.clear();
-    std::vector<LoadedMesh> loaded(nMesh);
-    for (int id : firstUseOrder) {
-        const rth_mesh_s& mesh = s->meshes[id];
-        MeshBuild& mb = builds[id];
-        int loadedBVsLength = (int)s->BVs.size();
-        int loadedTrianglesLength = (int)s->triangles.size();
-        int baseVertexIndex = (int)s->vertices.size();
-        LoadedMesh& lm = loaded[id];
-        lm.bvStartIndex = loadedBVsLength;
-        lm.componentStartIndex = loadedTrianglesLength;
-        lm.localMin = mb.nodes[0].mn;  // GetMin/GetMax over the mesh's triangles (:591)
-        lm.localMax = mb.nodes[0].mx;
-        lm.built = true;
-        for (BVNode bv : mb.nodes) {
-            if (bv.childIndexA != -1) bv.childIndexA += loadedBVsLength;
-            if (bv.childIndexB != -1) bv.childIndexB += loadedBVsLength;
-            bv.componentStart += loadedTrianglesLength;
-            s->BVs.push_back(toRenderBV(bv));
-            s->componentDatas.push_back({bv.componentStart, bv.totComponents});
-        }
-        bool containsUVs = true;  // .rtmesh always carries uvs ((-1,-1) where the OBJ had none)
-        (void)containsUVs;
-        for (const auto& v : mesh.verts) s->vertices.push_back(v);
-        for (const Comp& c : mb.comps) {  // RenderTriangle pack (:715-729), BVH-sorted order
-            rt_triangle t;
-            memset(&t, 0, sizeof t);
-            t.vertex0Index = mesh.tris[3 * (size_t)c.payload] + baseVertexIndex;
-            t.vertex1Index = mesh.tris[3 * (size_t)c.payload + 1] + baseVertexIndex;
-            t.vertex2Index = mesh.tris[3 * (size_t)c.payload + 2] + baseVertexIndex;
-            t.area = mb.area[(size_t)c.payload];
-            s->triangles.push_back(t);
-        }
-        mb = MeshBuild();
-    }
-
-    // ---- scene objects (:561-602) + ConstructSceneBVH (:609-664) ----
+    const std::vector<LoadedMesh>& loaded = s->loaded;
     std::vector<rt_scene_object> objs(nObj);
     int maxBVHDepth = s->maxDepthSceneBVH;
     double totArea = 0;  // rounded once at the end, see boxAreaStored
@@ -574,8 +448,177 @@ int rth_scene_build(rth_scene s, int threads) {
     s->maxBVHDepth = maxBVHDepth;
     s->emittingObjectsNum = emitting;
     s->sceneBVHStartIndex = sceneBVHStartIndex;
+    s->lastSceneBVHLength = (int)sb.nodes.size();
     s->totArea = (float)totArea;
     s->built = true;
+}
+
+}  // namespace
+
+extern "C" {
+
+rth_scene rth_scene_create(int splitResolution, int maxDepthSceneBVH) {
+    if (splitResolution < 1) return nullptr;
+    rth_scene s = new rth_scene_s;
+    s->splitResolution = splitResolution;
+    s->maxDepthSceneBVH = maxDepthSceneBVH;
+    return s;
+}
+void rth_scene_free(rth_scene s) { delete s; }
+int rth_scene_add_material(rth_scene s, const rth_material_input* m) {
+    if (!s || !m) return -1;
+    s->materialInputs.push_back(*m);
+    s->materialTextures.emplace_back();
+    return (int)s->materialInputs.size() - 1;
+}
+int rth_scene_add_material_textured(rth_scene s, const rth_material_input* m, const rth_texture_input tex[5]) {
+    if (!s || !m || !tex) return -1;
+    std::array<rth_scene_s::Tex, 5> t;
+    for (int k = 0; k < 5; k++) {
+        if (!tex[k].pixels) continue;
+        if (tex[k].width < 1 || tex[k].height < 1 || tex[k].width > 8192 || tex[k].height > 8192) return -1;
+        t[(size_t)k].w = tex[k].width; t[(size_t)k].h = tex[k].height;
+        t[(size_t)k].px.assign(tex[k].pixels, tex[k].pixels + (size_t)tex[k].width * tex[k].height * 4);
+    }
+    s->materialInputs.push_back(*m);
+    s->materialTextures.push_back(std::move(t));
+    return (int)s->materialInputs.size() - 1;
+}
+int rth_scene_add_mesh(rth_scene s, rth_mesh m) {
+    if (!s || !m) return -1;
+    s->meshes.push_back(*m);
+    return (int)s->meshes.size() - 1;
+}
+int rth_scene_add_object(rth_scene s, int meshId, const float position[3], const float eulerDeg[3], const float scale[3],
+                         int materialIndex, int maxDepthBVH) {
+    if (!s || meshId < 0 || meshId >= (int)s->meshes.size() || materialIndex < 0 ||
+        materialIndex >= (int)s->materialInputs.size())
+        return -1;
+    ObjectDesc o;
+    o.meshId = meshId;
+    memcpy(o.pos, position, 12);
+    memcpy(o.rot, eulerDeg, 12);
+    memcpy(o.scale, scale, 12);
+    o.materialIndex = materialIndex;
+    o.maxDepthBVH = maxDepthBVH;
+    s->objects.push_back(o);
+    return (int)s->objects.size() - 1;
+}
+
+void rth_world_to_local(const float position[3], const float eulerDeg[3], const float scale[3], float outW2L[16],
+                        float outL2W[16]) {
+    M4 w2l = createWorldToLocal(position, eulerDeg, scale);
+    M4 l2w = inverse(w2l);
+    memcpy(outW2L, w2l.m, 64);
+    memcpy(outL2W, l2w.m, 64);
+}
+
+int rth_scene_build(rth_scene s, int threads) {
+    if (!s || s->objects.empty()) return -1;
+    if (threads <= 0) threads = omp_get_max_threads();
+    const int nMesh = (int)s->meshes.size();
+
+    if (!rth_scene_make_materials(s)) return -1;
+
+    // ---- LoadSceneObjects (:556-607): meshes get their BVH the first time an object uses them ----
+    std::vector<int> firstUseOrder;          // mesh ids in order of first use
+    std::vector<int> meshMaxDepth(nMesh, 0); // the depth of the first object that uses the mesh
+    std::vector<char> used(nMesh, 0);
+    for (const auto& o : s->objects)
+        if (!used[o.meshId]) { used[o.meshId] = 1; firstUseOrder.push_back(o.meshId); meshMaxDepth[o.meshId] = o.maxDepthBVH; }
+
+    struct MeshBuild { std::vector<BVNode> nodes; std::vector<Comp> comps; std::vector<float> area; };
+    std::vector<MeshBuild> builds(nMesh);
+    const int nUse = (int)firstUseOrder.size();
+#pragma omp parallel for schedule(dynamic, 1) num_threads(threads)
+    for (int u = 0; u < nUse; u++) {
+        int id = firstUseOrder[u];
+        const rth_mesh_s& mesh = s->meshes[id];
+        MeshBuild& mb = builds[id];
+        size_t nt = mesh.tris.size() / 3;
+        mb.comps.resize(nt);
+        mb.area.resize(nt);
+        for (size_t t = 0; t < nt; t++) {  // Triangle.Initialise (Triangle.cs:17-46)
+            V3 v0 = toV3(mesh.verts[mesh.tris[3 * t]].pos), v1 = toV3(mesh.verts[mesh.tris[3 * t + 1]].pos),
+               v2 = toV3(mesh.verts[mesh.tris[3 * t + 2]].pos);
+            mb.comps[t].mn = vmin(vmin(v0, v1), v2);
+            mb.comps[t].mx = vmax(vmax(v0, v1), v2);
+            mb.comps[t].payload = (int32_t)t;
+            V3 ab = {v1.x - v0.x, v1.y - v0.y, v1.z - v0.z}, ac = {v2.x - v0.x, v2.y - v0.y, v2.z - v0.z};
+            V3 cr = {ab.y * ac.z - ab.z * ac.y, ab.z * ac.x - ab.x * ac.z, ab.x * ac.y - ab.y * ac.x};
+            mb.area[t] = sqrtf(cr.x * cr.x + cr.y * cr.y + cr.z * cr.z) * 0.5f;  // Func.GetTriArea (Resources.cs:294-301)
+        }
+        Builder b;
+        b.splitResolution = s->splitResolution;
+        b.build(mb.comps, meshMaxDepth[id]);
+        mb.nodes.swap(b.nodes);
+    }
+
+    // ---- concatenate in first-use order: ConstructBVH (:303-347) ----
+    s->BVs.clear(); s->componentDatas.clear(); s->vertices.clear(); s->triangles.clear();
+    std::vector<LoadedMesh>& loaded = s->loaded;
+    loaded.assign(nMesh, LoadedMesh());
+    for (int id : firstUseOrder) {
+        const rth_mesh_s& mesh = s->meshes[id];
+        MeshBuild& mb = builds[id];
+        int loadedBVsLength = (int)s->BVs.size();
+        int loadedTrianglesLength = (int)s->triangles.size();
+        int baseVertexIndex = (int)s->vertices.size();
+        LoadedMesh& lm = loaded[id];
+        lm.bvStartIndex = loadedBVsLength;
+        lm.componentStartIndex = loadedTrianglesLength;
+        lm.localMin = mb.nodes[0].mn;  // GetMin/GetMax over the mesh's triangles (:591)
+        lm.localMax = mb.nodes[0].mx;
+        lm.built = true;
+        for (BVNode bv : mb.nodes) {
+            if (bv.childIndexA != -1) bv.childIndexA += loadedBVsLength;
+            if (bv.childIndexB != -1) bv.childIndexB += loadedBVsLength;
+            bv.componentStart += loadedTrianglesLength;
+            s->BVs.push_back(toRenderBV(bv));
+            s->componentDatas.push_back({bv.componentStart, bv.totComponents});
+        }
+        bool containsUVs = true;  // .rtmesh always carries uvs ((-1,-1) where the OBJ had none)
+        (void)containsUVs;
+        for (const auto& v : mesh.verts) s->vertices.push_back(v);
+        for (const Comp& c : mb.comps) {  // RenderTriangle pack (:715-729), BVH-sorted order
+            rt_triangle t;
+            memset(&t, 0, sizeof t);
+            t.vertex0Index = mesh.tris[3 * (size_t)c.payload] + baseVertexIndex;
+            t.vertex1Index = mesh.tris[3 * (size_t)c.payload + 1] + baseVertexIndex;
+            t.vertex2Index = mesh.tris[3 * (size_t)c.payload + 2] + baseVertexIndex;
+            t.area = mb.area[(size_t)c.payload];
+            s->triangles.push_back(t);
+        }
+        mb = MeshBuild();
+    }
+
+    constructSceneLevel(s);
+    return 0;
+}
+
+// A GameObject moved (its SceneObjectSettings.LateUpdate would set Main.DoReloadData, SceneObjectSettings.cs:27-36).
+int rth_scene_set_object_transform(rth_scene s, int objectIndex, const float position[3], const float eulerDeg[3], const float scale[3]) {
+    if (!s || objectIndex < 0 || objectIndex >= (int)s->objects.size() || !position || !eulerDeg || !scale) return -1;
+    ObjectDesc& o = s->objects[(size_t)objectIndex];
+    memcpy(o.pos, position, 12);
+    memcpy(o.rot, eulerDeg, 12);
+    memcpy(o.scale, scale, 12);
+    return 0;
+}
+
+// ConstructScene called again on a built scene (Main.SetData on a reload, Main.cs:278): every mesh is found among the
+// loaded ones (ObjectHelper.cs:582-584), so no mesh BVH is rebuilt and the vertex and triangle arrays stay as they are;
+// the per-object data, the scene BVH and the light list are made anew.
+int rth_scene_rebuild(rth_scene s, int keepOldSceneBVH) {
+    if (!s || !s->built) return -1;
+    if (s->objects.empty()) return 0;  // filled from a scene cache: LoadExistingFile reads the same files again (:672-677)
+    for (const auto& o : s->objects)
+        if (o.meshId < 0 || o.meshId >= (int)s->loaded.size() || !s->loaded[(size_t)o.meshId].built) return -1;
+    if (!keepOldSceneBVH) {  // Utils.RemoveFromEndOfArray(ref loadedBoundingVolumes, lastSceneBVHLength), MeshHelper.cs:371-372
+        s->BVs.resize(s->BVs.size() - (size_t)s->lastSceneBVHLength);
+        s->componentDatas.resize(s->componentDatas.size() - (size_t)s->lastSceneBVHLength);
+    }
+    constructSceneLevel(s);
     return 0;
 }
 

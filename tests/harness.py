@@ -106,29 +106,46 @@ class OracleRenderer:
         self.lib = oracle_lib()
         self.cfg = cfg
         self.threads = threads
-        self.a = {k: (v.copy() if isinstance(v, np.ndarray) else v) for k, v in scene_arrays.items()}
         W, H = cfg.Resolution[0], cfg.Resolution[1]
         self.W, self.H = W, H
         n = W * H
-        self.buf = {
-            "HitInfos": np.zeros(n, DT["HitInfo"]), "Candidates": np.zeros(n, DT["Reservoir"]),
-            "CandidatesB": np.zeros(n, DT["Reservoir"]), "TemporalFrameBuffer": np.zeros(n, DT["Reservoir"]),
-        }
         self.tex = {k: np.zeros((H, W, 4), np.float32) for k in ("Result", "AccumulatedResult", "DebugOverlay",
                                                                   "NormalsBuffer", "RayHitPointsA", "RayHitPointsB")}
         self.tex["DepthBuffer"] = np.zeros((H, W), np.float32)
         self.records = np.zeros(n, DT["TraceRecord"]) if records else None
-        # the RGBA8 atlas as the library converts it on upload: texel / 255 in fp32
-        self.atlas = np.ascontiguousarray(self.a["atlas"].astype(np.float32) / np.float32(255.0)) if "atlas" in self.a \
-            else np.zeros((1, 1, 4), np.float32)
         self.env = np.array([[[0.5, 0.7, 1.0, 1.0]]], np.float32)
         self.counters = OrcCounters()
         self.FrameCount = 0
         self.frames_started = 0
+        self.pending_reload = None
         self.p = OrcParams()
+        self.f = OrcFrame()
+        for k, v in self.tex.items():
+            setattr(self.f, k, v.ctypes.data)
+        self.f.records = self.records.ctypes.data if records else None
+        self.f.counters = C.addressof(self.counters)
+        self.camera = ([float(x) for x in cfg.cameraPosition], [float(x) for x in cfg.cameraRotation])
+        self.last_camera = self.camera
+        self._set_data(scene_arrays)
         self._static_params(row0, row1)
+        # Main.Start (Main.cs:105-115) runs SetCameraData before the first frame: "last" starts as the initial camera
+        self._set_camera_data()
+
+    def _set_data(self, scene_arrays):
+        """Main.SetData (Main.cs:273-310): the scene arrays as ConstructScene returns them now, CalcTriNormals on them,
+        and four new (zeroed) per-pixel buffers.  The render targets are not touched."""
+        a = self.a = {k: (v.copy() if isinstance(v, np.ndarray) else v) for k, v in scene_arrays.items()}
+        n = self.W * self.H
+        self.buf = {
+            "HitInfos": np.zeros(n, DT["HitInfo"]), "Candidates": np.zeros(n, DT["Reservoir"]),
+            "CandidatesB": np.zeros(n, DT["Reservoir"]), "TemporalFrameBuffer": np.zeros(n, DT["Reservoir"]),
+        }
+        for k in ("HitInfos", "Candidates", "CandidatesB", "TemporalFrameBuffer"):
+            setattr(self.f, k, self.buf[k].ctypes.data)
+        # the RGBA8 atlas as the library converts it on upload: texel / 255 in fp32
+        self.atlas = np.ascontiguousarray(a["atlas"].astype(np.float32) / np.float32(255.0)) if "atlas" in a \
+            else np.zeros((1, 1, 4), np.float32)
         s = OrcScene()
-        a = self.a
         s.BVs, s.nBVs = a["BVs"].ctypes.data, len(a["BVs"])
         s.SceneObjects, s.nSceneObjects = a["SceneObjects"].ctypes.data, len(a["SceneObjects"])
         s.LightObjects, s.nLightObjects = a["LightObjects"].ctypes.data, len(a["LightObjects"])
@@ -138,15 +155,7 @@ class OracleRenderer:
         s.TextureAtlas, s.atlasW, s.atlasH = self.atlas.ctypes.data, self.atlas.shape[1], self.atlas.shape[0]
         s.EnvironmentMap, s.envW, s.envH = self.env.ctypes.data, 1, 1
         self.s = s
-        f = OrcFrame()
-        for k in ("HitInfos", "Candidates", "CandidatesB", "TemporalFrameBuffer"):
-            setattr(f, k, self.buf[k].ctypes.data)
-        for k, v in self.tex.items():
-            setattr(f, k, v.ctypes.data)
-        f.records = self.records.ctypes.data if records else None
-        f.counters = C.addressof(self.counters)
-        self.f = f
-        self.lib.orc_calc_tri_normals(C.byref(self.s), threads)  # RunPreCalcShader, Main.cs:294
+        self.lib.orc_calc_tri_normals(C.byref(self.s), self.threads)  # RunPreCalcShader, Main.cs:294
 
     def _static_params(self, row0, row1):
         p, cfg, a = self.p, self.cfg, self.a
@@ -160,10 +169,6 @@ class OracleRenderer:
         host.rth_view_space_dims(cfg.fieldOfView, cfg.Resolution[0], cfg.Resolution[1], vsd)
         p.ViewSpaceDims[0], p.ViewSpaceDims[1] = vsd[0], vsd[1]
         p.DefocusStrength, p.FocalPlaneFactor = cfg.DefocusStrength, cfg.FocalPlaneFactor
-        # Main.Start (Main.cs:105-115) runs SetCameraData before the first frame: "last" starts as the initial camera
-        self.camera = ([float(x) for x in cfg.cameraPosition], [float(x) for x in cfg.cameraRotation])
-        self.last_camera = self.camera
-        self._set_camera_data()
         p.unorm8Targets = cfg.Unorm8RenderTargets
         p.DebugDataMaxValues[0], p.DebugDataMaxValues[1] = cfg.DebugMaxTriChecks, cfg.DebugMaxBVChecks
         p.SceneObjectReservoirTestsNum, p.TriReservoirTestsNum = cfg.SceneObjectReservoirTestsNum, cfg.TriReservoirTestsNum
@@ -203,7 +208,13 @@ class OracleRenderer:
         self.last_camera = self.camera
 
     # ---- Main.cs sequence ----
+    def reload(self, scene_arrays=None, cfg=None):
+        """DoUpdateSettings + DoReloadData (Main.cs:206-209, SceneObjectSettings.cs:27-36): carried out by the next
+        update_per_frame.  scene_arrays: what ConstructScene returns now (None: the scene is unchanged)."""
+        self.pending_reload = (scene_arrays if scene_arrays is not None else self.a, cfg)
+
     def update_per_frame(self):
+        """Main.Update (Main.cs:117-132): UpdatePerFrame, then UpdateSettings(true) if a reload was requested."""
         cfg = self.cfg
         self.p.FrameRand = (cfg.frameRandBase + cfg.frameRandStep * self.frames_started) % 999999
         self.frames_started += 1
@@ -211,6 +222,14 @@ class OracleRenderer:
         self.pp_frame_count = self.FrameCount
         self.FrameCount += 1
         self._set_camera_data()
+        if self.pending_reload is not None:   # UpdateSettings(true), Main.cs:211-271
+            arrays, new_cfg = self.pending_reload
+            self.pending_reload = None
+            self.FrameCount = 0               # the shader keeps the count pushed above for this frame
+            if new_cfg is not None:
+                self.cfg = new_cfg
+            self._set_data(arrays)
+            self._static_params(self.p.row0, self.p.row1)   # (UpdateSettings pushes no camera constants)
 
     def _run(self, fn):
         rc = fn(C.byref(self.s), C.byref(self.p), C.byref(self.f), self.threads)
@@ -345,20 +364,36 @@ class RisOracleRenderer:
     def __init__(self, scene_arrays, cfg, threads=0, records=True, row0=0, row1=0):
         self.lib = oracle_ris_lib()
         self.cfg, self.threads = cfg, threads
-        a = self.a = {k: (v.copy() if isinstance(v, np.ndarray) else v) for k, v in scene_arrays.items()}
-        self.tris, self.mats = ris_arrays_from_scene(a, cfg.smoothness)
         W, H = cfg.Resolution[0], cfg.Resolution[1]
         self.W, self.H = W, H
         n = W * H
-        rpp = 1  # Main.Start forces RaysPerPixel to 1 (Main.cs:92-97)
-        tot = cfg.SceneObjectCandidatesNum * cfg.TriCandidatesNum
-        self.buf = {"HitInfos": np.zeros(n, DT["RisHitInfo"]), "Candidates": np.zeros(max(n * rpp * tot, 1), DT["Float4"])}
         self.tex = {k: np.zeros((H, W, 4), np.float32) for k in ("Result", "AccumulatedResult", "DebugOverlay", "RayHitPoints")}
         self.records = np.zeros(n, DT["TraceRecord"]) if records else None
         self.counters = OrcCounters()
         self.FrameCount = 0
         self.frames_started = 0
-        p = self.p = OrcRisParams()
+        self.pending_reload = None
+        self.p = OrcRisParams()
+        self.p.row0, self.p.row1 = row0, row1
+        f = self.f = OrcRisFrame()
+        f.Result, f.DebugOverlay = self.tex["Result"].ctypes.data, self.tex["DebugOverlay"].ctypes.data
+        f.RayHitPoints = self.tex["RayHitPoints"].ctypes.data
+        f.records = self.records.ctypes.data if records else None
+        f.counters = C.addressof(self.counters)
+        self._update_settings(scene_arrays)
+
+    def _update_settings(self, scene_arrays):
+        """Main.UpdateSettings -> SetData (BVH_RIS_DL Main.cs:221-312): every constant, the scene arrays as the builder
+        returns them now, new (zeroed) Candidates and HitInfos buffers, CalcTriNormals."""
+        cfg, threads = self.cfg, self.threads
+        a = self.a = {k: (v.copy() if isinstance(v, np.ndarray) else v) for k, v in scene_arrays.items()}
+        self.tris, self.mats = ris_arrays_from_scene(a, cfg.smoothness)
+        W, H = self.W, self.H
+        n = W * H
+        rpp = 1  # Main.Start forces RaysPerPixel to 1 (Main.cs:92-97)
+        tot = cfg.SceneObjectCandidatesNum * cfg.TriCandidatesNum
+        self.buf = {"HitInfos": np.zeros(n, DT["RisHitInfo"]), "Candidates": np.zeros(max(n * rpp * tot, 1), DT["Float4"])}
+        p = self.p
         host = rt.host_lib()
         p.TrisNum, p.BVsNum = len(self.tris), len(a["BVs"])
         p.MaxBVHDepth, p.SceneBVHStartIndex = a["maxBVHDepth"], a["sceneBVHStartIndex"]
@@ -380,7 +415,6 @@ class RisOracleRenderer:
         p.SceneObjectCandidatesNum, p.TriCandidatesNum, p.TotCandidatesNum = cfg.SceneObjectCandidatesNum, cfg.TriCandidatesNum, tot
         p.SceneObjectReservoirTestsNum, p.TriReservoirTestsNum = cfg.SceneObjectReservoirTestsNum, cfg.TriReservoirTestsNum
         p.CandidateReservoirTestsNum = cfg.CandidateReservoirTestsNum
-        p.row0, p.row1 = row0, row1
         p.unorm8Targets = cfg.Unorm8RenderTargets
         s = self.s = OrcRisScene()
         s.BVs, s.nBVs = a["BVs"].ctypes.data, len(a["BVs"])
@@ -388,25 +422,30 @@ class RisOracleRenderer:
         s.LightObjects, s.nLightObjects = a["LightObjects"].ctypes.data, len(a["LightObjects"])
         s.Materials, s.nMaterials = self.mats.ctypes.data, len(self.mats)
         s.Tris, s.nTris = self.tris.ctypes.data, len(self.tris)
-        f = self.f = OrcRisFrame()
+        f = self.f
         f.HitInfos, f.nHitInfos = self.buf["HitInfos"].ctypes.data, n
         f.Candidates, f.nCandidates = self.buf["Candidates"].ctypes.data, len(self.buf["Candidates"])
-        f.Result, f.DebugOverlay = self.tex["Result"].ctypes.data, self.tex["DebugOverlay"].ctypes.data
-        f.RayHitPoints = self.tex["RayHitPoints"].ctypes.data
-        f.records = self.records.ctypes.data if records else None
-        f.counters = C.addressof(self.counters)
         assert self.lib.orc_ris_calc_tri_normals(C.byref(s), len(self.tris), threads) == 0  # RunPreCalcShader, Main.cs:298
 
     def set_band(self, row0, row1):
         self.p.row0, self.p.row1 = row0, row1
 
+    def reload(self, scene_arrays=None):
+        """DoUpdateSettings (BVH_RIS_DL Main.cs:117,126,218): carried out by the next update_per_frame."""
+        self.pending_reload = scene_arrays if scene_arrays is not None else self.a
+
     def update_per_frame(self):
+        """Main.Update (BVH_RIS_DL Main.cs:105-120): UpdatePerFrame, then UpdateSettings if one was requested."""
         cfg = self.cfg
         self.p.FrameRand = (cfg.frameRandBase + cfg.frameRandStep * self.frames_started) % 999999
         self.frames_started += 1
         self.p.FrameCount = self.FrameCount
         self.pp_frame_count = self.FrameCount
         self.FrameCount += 1
+        if self.pending_reload is not None:
+            arrays, self.pending_reload = self.pending_reload, None
+            self.FrameCount = 0
+            self._update_settings(arrays)
 
     def generate_candidates(self):
         assert self.lib.orc_ris_generate_candidates(C.byref(self.s), C.byref(self.p), C.byref(self.f), self.threads) == 0

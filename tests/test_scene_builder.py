@@ -59,3 +59,48 @@ def test_view_space_dims_integer_aspect():
     assert abs(out[1] - np.tan(np.radians(35.0))) < 1e-6 and out[0] == out[1]   # 1920/1080 == 1 in integer division
     rt.host_lib().rth_view_space_dims(70.0, 3840, 1080, out)
     assert abs(out[0] - 3 * out[1]) < 1e-6
+
+
+def _grid_scene():
+    return rt.build_scene_instanced(grid=(3, 2), emissive_objects=2, emissive_tris=16, unique=False, subdivide=False)
+
+
+def test_rebuild_after_a_move_keeps_meshes_and_appends_the_scene_bvh():
+    """ConstructScene called again (ObjectHelper.cs:666-738): mesh BVHs, vertices and triangles are kept, the per-object
+    data, scene BVH and light list equal those of a scene built with the object at its new place, and - the ReSTIR
+    project never drops the old scene BVH (:38,613-614) - the new scene nodes sit behind the old ones."""
+    pos, rot, scale = (5.0, 1.0, 20.0), (10.0, 40.0, 0.0), (8.0, 8.0, 8.0)
+    moved = _grid_scene()
+    before = moved.arrays()
+    moved.set_object_transform(4, pos, rot, scale)
+    moved.rebuild()
+    after = moved.arrays()
+
+    ref = _grid_scene()
+    ref.set_object_transform(4, pos, rot, scale)
+    ref.rebuild(keep_old_scene_bvh=False)      # the RIS project's builder replaces the scene BVH (MeshHelper.cs:371-372)
+    want = ref.arrays()
+
+    n_mesh_nodes = before["sceneBVHStartIndex"]
+    n_scene_old = len(before["BVs"]) - n_mesh_nodes
+    assert after["sceneBVHStartIndex"] == len(before["BVs"])
+    assert want["sceneBVHStartIndex"] == n_mesh_nodes
+    for k in ("Vertices", "Triangles"):
+        assert np.array_equal(h.bits(after[k]), h.bits(before[k])), k
+    assert np.array_equal(h.bits(after["BVs"][:len(before["BVs"])]), h.bits(before["BVs"]))   # mesh BVHs + the stale scene BVH
+    assert np.array_equal(h.bits(after["SceneObjects"]), h.bits(want["SceneObjects"]))
+    assert np.array_equal(h.bits(after["LightObjects"]), h.bits(want["LightObjects"]))
+    assert after["totArea"] == want["totArea"] and after["emittingObjectsNum"] == want["emittingObjectsNum"]
+    # the new scene BVH is the replaced one shifted behind the stale nodes
+    new, rep = after["BVs"][after["sceneBVHStartIndex"]:], want["BVs"][n_mesh_nodes:]
+    assert len(new) == len(rep)
+    assert np.array_equal(new["min"], rep["min"]) and np.array_equal(new["max"], rep["max"])
+    internal = rep["indexA"] < 0
+    assert np.array_equal(new["indexA"][internal], rep["indexA"][internal] - n_scene_old)
+    assert np.array_equal(new["indexB"][internal], rep["indexB"][internal] - n_scene_old)
+    assert np.array_equal(new["indexA"][~internal], rep["indexA"][~internal])
+    assert np.array_equal(new["indexB"][~internal], rep["indexB"][~internal])
+    # the moved object's matrices are CreateWorldToLocalMatrix of the new transform
+    w2l, l2w = rt.world_to_local(pos, rot, scale)
+    assert any(np.array_equal(o["worldToLocal"], w2l) and np.array_equal(o["localToWorld"], l2w) for o in after["SceneObjects"])
+    assert not np.array_equal(h.bits(after["SceneObjects"]), h.bits(before["SceneObjects"]))

@@ -15,7 +15,16 @@ pytestmark = pytest.mark.gpu
 
 BUFFERS = ("HitInfos", "Candidates", "CandidatesB", "TemporalFrameBuffer")
 TEXTURES = ("DepthBuffer", "NormalsBuffer", "DebugOverlay", "RayHitPointsA", "RayHitPointsB", "Result", "AccumulatedResult")
-RT_ERR_LIMIT, RT_ERR_NOT_PREPARED = -6, -7
+RT_ERR_LIMIT, RT_ERR_NOT_PREPARED, RT_ERR_BUSY = -6, -7, -9
+
+
+def device_free_bytes():
+    """hipMemGetInfo: the free bytes of the current device (an allocation of any size moves it)."""
+    import ctypes as C
+    hip = C.CDLL("libamdhip64.so")
+    free, total = C.c_size_t(), C.c_size_t()
+    assert hip.hipMemGetInfo(C.byref(free), C.byref(total)) == 0
+    return free.value
 
 
 def no_alloc_frame(ctx, drv, cfg):
@@ -51,7 +60,6 @@ def snapshot(drv):
 
 def run_pair(ctx, scene, res, frames):
     cfg = h.small_config(*res)
-    # the context caches the traversal arrays of ONE set of scene buffers, so the two drivers run one after the other
     ref = rt.Driver(ctx, cfg, scene)
     want = []
     try:
@@ -66,7 +74,10 @@ def run_pair(ctx, scene, res, frames):
         sut.render_frame()
         ctx.sync()
         for frame in range(1, frames + 1):
+            free_before = device_free_bytes()
             no_alloc_frame(ctx, sut, cfg)
+            ctx.sync()
+            assert device_free_bytes() == free_before, "a no-alloc frame changed the device's free memory"
             got = snapshot(sut)
             for k in got:
                 assert np.array_equal(h.bits(want[frame][k]), h.bits(got[k])), f"{res} frame {frame}: {k} differs"
@@ -108,3 +119,47 @@ def test_no_alloc_refuses_what_needs_an_allocation(gpu_ctx, scene_small):
         lib.rt_shader_close(sh)
     finally:
         drv.close()
+
+
+def test_two_scenes_on_one_context_stay_prepared(gpu_ctx, scene_small):
+    """The context keeps the traversal arrays of several sets of scene buffers: two drivers (each with its own upload of
+    the scene) alternate frames, and neither's rt_dispatch_no_alloc finds its arrays gone."""
+    cfg = h.small_config(64, 48)
+    a, b = rt.Driver(gpu_ctx, cfg, scene_small), rt.Driver(gpu_ctx, cfg, scene_small)
+    try:
+        a.render_frame()
+        b.render_frame()
+        gpu_ctx.sync()
+        for _ in range(2):
+            no_alloc_frame(gpu_ctx, a, cfg)
+            no_alloc_frame(gpu_ctx, b, cfg)
+        sa, sb = snapshot(a), snapshot(b)
+        for k in sa:
+            assert np.array_equal(h.bits(sa[k]), h.bits(sb[k])), k
+    finally:
+        a.close()
+        b.close()
+
+
+def test_second_context_is_refused_while_the_scratch_is_in_use(gpu_ctx, scene_80k):
+    """Every context of a GPU shares the scratch array: a no-alloc dispatch from another context is refused while the
+    first one's launches are still in flight, and accepted once they are done."""
+    lib = gpu_ctx.lib
+    cfg = h.small_config(1920, 1080)
+    other = rt.RtContext(0)
+    drv = rt.Driver(gpu_ctx, cfg, scene_80k)
+    try:
+        drv.render_frame()
+        gpu_ctx.sync()
+        for _ in range(6):                       # several milliseconds of work on gpu_ctx's stream
+            no_alloc_frame(gpu_ctx, drv, cfg)
+        sh = other.open_shader("PostProcessor")
+        rc = lib.rt_dispatch_no_alloc(sh, 0, 8, 8, 1)
+        assert rc == RT_ERR_BUSY, rc
+        assert b"scratch" in lib.rt_last_error(other.h)
+        gpu_ctx.sync()
+        assert lib.rt_dispatch_no_alloc(sh, 0, 8, 8, 1) != RT_ERR_BUSY   # (unbound textures: another error, not this one)
+        lib.rt_shader_close(sh)
+    finally:
+        drv.close()
+        other.close()
