@@ -78,6 +78,19 @@ void* rt_stream(rt_ctx ctx);
  * A host that keeps the stream from an earlier rt_stream() call and waits on it by its own means calls this after
  * the last dispatch of a frame.  No counterpart in the reference. */
 int rt_flush(rt_ctx ctx);
+/* Primary rays of the next frames beside the kernels of the frames before.  InitialTrace's primary rays (and the RIS
+ * project's GenerateCandidates') depend on nothing the frames before compute; the library keeps a second copy of what
+ * they overwrite while it is still being read (HitInfos, DepthBuffer, RayHitPointsA/B), makes the copy it writes the
+ * current one at every such dispatch, and launches them on a stream of its own beside the kernels the dispatch stream
+ * still holds; the dispatch stream waits for them before the candidate kernel.  Nothing a host can observe changes:
+ * every readback, map and sync is ordered behind that wait, and buffers and textures read back what the dispatches, in
+ * call order, left in them.  mode 0: off (RT_OVERLAP=0 for a process); 1 (default): for InitialTrace dispatches that
+ * cover the whole image; 2: also for dispatches on a row band (rt_set_row_band) - the rows of HitInfos, DepthBuffer
+ * and RayHitPointsA/B outside the band are then undefined after the dispatch, which is fine for a host that renders
+ * the same band every frame (the multi-GPU frame loop) and wrong for one that renders several bands of one frame one
+ * after the other.  Device pointers from rt_buffer_map_rows / rt_texture_map_rows of those four objects are valid until
+ * the next such dispatch.  No counterpart in the reference. */
+int rt_set_overlap(rt_ctx ctx, int mode);
 /* enabled = 0: every dispatch is launched by the call that makes it (nothing is held or merged); 1 (the default
  * unless RT_FUSE=0 is in the environment): consecutive dispatches that can run as one launch do.  Results are
  * bit-identical either way.  No counterpart in the reference. */
@@ -199,7 +212,9 @@ void rt_texture_release(rt_texture tex);
  * the padded 64-byte records the reservoirs gathered by SpatialReusePass are kept in) or four runs (plane layout).  A multi-GPU host maps the border rows of the reservoir buffers and of
  * DepthBuffer right before each exchange and sends/receives them between the per-GPU processes (RCCL); row r of
  * one process's buffer corresponds to row r of every other's, because each process keeps full-frame buffers and
- * only renders its band.  The pointers are valid until the next call that uploads to or releases the object. */
+ * only renders its band.  The pointers are valid until the next call that uploads to or releases the object (for
+ * HitInfos, DepthBuffer and RayHitPointsA/B also: until the next InitialTrace / GenerateCandidates dispatch, see
+ * rt_set_overlap). */
 typedef struct {
     void* ptr;
     size_t bytes;

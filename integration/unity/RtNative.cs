@@ -31,6 +31,7 @@ internal static class RtNative
     [DllImport(Lib)] public static extern IntPtr rt_stream(IntPtr ctx);
     [DllImport(Lib)] public static extern int rt_flush(IntPtr ctx);
     [DllImport(Lib)] public static extern int rt_set_fusion(IntPtr ctx, int enabled);
+    [DllImport(Lib)] public static extern int rt_set_overlap(IntPtr ctx, int mode);
     [DllImport(Lib)] public static extern int rt_set_row_band(IntPtr ctx, int row0, int row1);
 
     // shaders

@@ -116,6 +116,8 @@ struct KParams {
     uint32_t* blockCost;       // InitialTrace only, may be null: hit pixels per wave, [(by * blocksX + bx) * 4 + wave]
     uint32_t* blockSteps;      // TraceRays only, may be null: steps each wave needed for its rays, same indexing
     int blocksX;               // blocks per image row of this launch's grid
+    uint32_t* bgCounter;       // background primary-ray launch only: next table round of each XCD (8 counters, zeroed per launch)
+    uint32_t bgBlocks;         // ... and the number of table entries
     unsigned long long* stats;  // sharded counters (rt_dispatch_stats order) or null
     int32_t statsLevel;         // 1: rays only, 2: everything
     uint32_t* records;          // 8 dwords per pixel (trace record) or null

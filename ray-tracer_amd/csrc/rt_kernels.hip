@@ -213,8 +213,8 @@ DEV v3 matCol(const KParams& P, const rt_material& m, v2 uv) {
 // land on one XCD (launch index mod 8, the observed round-robin placement; used for speed only) render compact
 // image regions, and the regions are dealt evenly to the XCDs.
 struct Pixel { int x, y; bool active; };
-DEV Pixel pixelOfThread(const KParams& P) {
-    const uint32_t m = P.blockMap[blockIdx.x];
+DEV Pixel pixelOfThread(const KParams& P, uint32_t launchBlock) {
+    const uint32_t m = P.blockMap[launchBlock];
     const uint32_t bx = m & 0xffffu, by = m >> 16;
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     Pixel p;
@@ -225,16 +225,18 @@ DEV Pixel pixelOfThread(const KParams& P) {
 }
 
 // Cost estimate of this wave's tile for the launches that follow the primary-ray kernel: its number of hit pixels.
-DEV void writeTileCost(const KParams& P, bool hit) {
+DEV Pixel pixelOfThread(const KParams& P) { return pixelOfThread(P, blockIdx.x); }
+DEV void writeTileCost(const KParams& P, bool hit, uint32_t launchBlock) {
     if (!P.blockCost) return;
     const unsigned long long hitMask = __builtin_amdgcn_ballot_w64(hit);
-    const uint32_t m = P.blockMap[blockIdx.x];
+    const uint32_t m = P.blockMap[launchBlock];
     if ((threadIdx.x & 63) == 0 && m != 0xffffffffu)
         P.blockCost[((size_t)(m >> 16) * P.blocksX + (m & 0xffffu)) * 4 + (threadIdx.x >> 6)] = (uint32_t)__builtin_popcountll(hitMask);
 }
 
 // Measured cost of this wave's tile: the steps the wave needed for its secondary rays (0 in lanes that cast none).  The
 // regions of the image are ranked by it for the launches of the following frames (k_order_blocks).
+DEV void writeTileCost(const KParams& P, bool hit) { writeTileCost(P, hit, blockIdx.x); }
 DEV void writeTileSteps(const KParams& P, uint32_t steps) {
     if (!P.blockSteps) return;
     for (int off = 32; off > 0; off >>= 1) { const uint32_t o = __shfl_xor(steps, off, 64); steps = o > steps ? o : steps; }
@@ -722,10 +724,10 @@ DEV v2 GetLastUV(const KParams& P, v3 worldFocalPos) {  // RS:451-461
 #ifndef RT_PRIMARY_WAVES
 #define RT_PRIMARY_WAVES 5
 #endif
+// The work of one workgroup of the launch: `launchBlock` = its entry of the block table.
 template <bool INSTR>
-__global__ __launch_bounds__(256, RT_PRIMARY_WAVES) void k_primary(const KParams P) {
-    extern __shared__ uint32_t lds[];
-    const Pixel px = pixelOfThread(P);
+DEV void primaryBlock(const KParams& P, uint32_t launchBlock, uint32_t* lds) {
+    const Pixel px = pixelOfThread(P, launchBlock);
     uint32_t rays = 0;
     Trav t;
     t.dst = INF();
@@ -769,7 +771,7 @@ __global__ __launch_bounds__(256, RT_PRIMARY_WAVES) void k_primary(const KParams
             r[5] = 0; r[6] = 0xffffffffu; r[7] = 0;
         }
     }
-    writeTileCost(P, px.active && t.dst != INF());
+    writeTileCost(P, px.active && t.dst != INF(), launchBlock);
     if (INSTR && P.waveProfile && P.waveProfileKernel == 0) writeWaveProfile(P, tStart, px.active ? t.iters : 0, t);
     if (P.stats) {
         waveAdd(P.stats + ST_RAYS, rays);
@@ -781,6 +783,29 @@ __global__ __launch_bounds__(256, RT_PRIMARY_WAVES) void k_primary(const KParams
             waveAdd(P.stats + ST_TRIITERS, px.active ? t.triIters : 0);
             waveAdd(P.stats + ST_TRICHECKS, px.active ? (uint32_t)t.triChecks : 0);
         }
+    }
+}
+// BG ("background"): the launch has only a few resident workgroups (P.bgGroups, a multiple of 8), each of which renders
+// block after block of the table until the table is used up, so that the primary rays of the NEXT frame can run for the
+// whole length of the frame before without taking more than a fraction of the chip's wave slots from its kernels.
+// Workgroup w runs on XCD w mod 8 and takes the table entries 8k + (w mod 8), k from a counter of that XCD: the entries
+// the block table has laid out for that XCD (rt_native.hip: buildBlockMap, k_order_blocks), in its order.
+template <bool INSTR, bool BG = false>
+__global__ __launch_bounds__(256, RT_PRIMARY_WAVES) void k_primary(const KParams P) {
+    extern __shared__ uint32_t lds[];
+    if (!BG) {
+        primaryBlock<INSTR>(P, blockIdx.x, lds);
+        return;
+    }
+    __shared__ uint32_t nextEntry;
+    const uint32_t xcd = blockIdx.x & 7u;
+    for (;;) {   // ends for every workgroup: the counter only grows, and P.bgBlocks is fixed
+        if (threadIdx.x == 0) nextEntry = atomicAdd(&P.bgCounter[xcd], 1u) * 8u + xcd;
+        __syncthreads();
+        const uint32_t entry = nextEntry;
+        __syncthreads();   // (all four waves have read it before the next round overwrites it)
+        if (entry >= P.bgBlocks) break;
+        primaryBlock<INSTR>(P, entry, lds);
     }
 }
 

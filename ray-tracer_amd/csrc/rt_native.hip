@@ -53,8 +53,41 @@ static rt_ctx_s* scratchOwner[SCRATCH_MAX_DEVICES] = {};
 
 struct rt_ctx_s {
     int device = 0;
-    // The dispatch stream.  Every use goes through S(ctx), which first launches a held-back dispatch (see Deferred).
+    // The dispatch stream.  Every use goes through S(ctx) or SK(ctx), which first launch a held-back dispatch (see Deferred).
     hipStream_t stream0 = nullptr;
+    // Primary rays of the NEXT frames beside the kernels of the frames before.  InitialTrace's primary-ray kernel (and the
+    // RIS project's) reads nothing any kernel of the frame sequence produces; it only OVERWRITES per-pixel data that
+    // kernels of the frame before still read: HitInfos and DepthBuffer (candidate kernel, SpatialReusePass,
+    // TransferToOriginal, TraceRays) and the hit-point target of its parity (TemporalReuse reads both targets).  The
+    // library keeps a second copy of each of those, writes the copy that is NOT current and makes it the current one
+    // at the dispatch, and launches the primary rays on `stream1`, where they queue behind one another and run beside
+    // whatever stream0 holds; stream0 waits for them (`evPrimary`) before the candidate kernel.  The copy being written
+    // was last read by the frame before the previous one: `evReaders[k]`, recorded on stream0 at every such dispatch
+    // (alternately k = 0, 1), marks where those readers end, and stream1 waits for the older of the two.
+    // Everything a host can observe stays in call order: every readback, map and sync goes through stream0, which has
+    // the wait for the primary rays enqueued by the time the dispatch returns, and reads the current copies.
+    // `mainDirty`: something other than the frame's own kernels was put on stream0 since (a scene rebuild, a cleared new
+    // buffer, primary rays that could not be overlapped, work of the host's own after rt_stream): the next primary
+    // rays then wait for all of stream0.
+    // overlap: 0 off, 1 (default) InitialTrace dispatches that cover the whole image, 2 also those on a row band (the
+    // rows outside the band are then undefined in the flipped objects: a multi-GPU host never reads them).
+    hipStream_t stream1 = nullptr;
+    hipEvent_t evReaders[2] = {nullptr, nullptr}, evPrimary = nullptr;
+    bool readersValid[2] = {false, false};
+    int ring = 0;
+    // By choice (the default) the primary rays also wait for `evAfterCandidates`, recorded on stream0 behind every
+    // candidate-kernel launch: they then run beside the previous frame's SpatialReusePass and TraceRays launches only,
+    // not beside its candidate kernel, which measured a little faster on one GPU (0.745 against 0.756 ms per 1080p frame,
+    // 2.43 against 2.47 ms at 3840x2160).
+    hipEvent_t evAfterCandidates = nullptr;
+    bool afterCandidatesValid = false;
+    bool behindCandidates = true;
+    bool mainDirty = true;
+    int overlap = 1;
+    // Overlapped primary rays as a "background" launch (k_primary<.., BG>): bgGroups resident workgroups (0 = an
+    // ordinary launch) walk the block table through bgCounter (8 words, one per XCD, cleared on stream1 before each launch).
+    int bgGroups = 0;
+    uint32_t* bgCounter = nullptr;
     hipStream_t transferStream = nullptr;  // created by rt_transfer_stream
     hipEvent_t orderEvent[2] = {nullptr, nullptr};
     hipEvent_t marks[64] = {};
@@ -66,7 +99,7 @@ struct rt_ctx_s {
     // dev: the static order; dyn: the heaviest-first order k_order_blocks rebuilds after InitialTrace's primary rays, from the
     // per-wave hit counts in cost until a TraceRays has run on this grid, then from the steps its waves needed (steps);
     // null when the grid has more regions than that kernel sorts
-    struct BlockMap { int bx, by; uint32_t* dev; unsigned n; uint32_t* dyn; uint32_t* cost; unsigned nDyn; bool dynValid; unsigned age; uint32_t* steps; bool stepsValid; bool rankedBySteps; uint32_t* dynHits; };
+    struct BlockMap { int bx, by; uint32_t* dev; unsigned n; uint32_t* dyn; uint32_t* cost; unsigned nDyn; bool dynValid; unsigned age; uint32_t* steps; bool stepsValid; bool rankedBySteps; uint32_t* dynHits; bool pendingDyn; bool pendingMeasured; };
     std::vector<BlockMap> blockMaps;  // one per band height in use (a multi-GPU host alternates between a few)
     uint32_t* scratch = nullptr;  // this device's address of the file-scope `scratch` array
     bool noAlloc = false;         // set for the duration of rt_dispatch_no_alloc
@@ -133,6 +166,7 @@ struct rt_buffer_s {
     void* dev;
     int layout;
     uint64_t version;
+    void* alt = nullptr;  // HitInfos only: the copy the next frame's primary rays write (see rt_ctx_s::stream1)
 };
 
 struct rt_texture_s {
@@ -142,6 +176,7 @@ struct rt_texture_s {
     void* dev;     // float (R32F) or float4 (others) texels
     size_t bytes;  // device bytes
     uint64_t version;  // bumped by every upload
+    void* alt = nullptr;  // DepthBuffer only: the copy the next frame's primary rays write (see rt_ctx_s::stream1)
 };
 
 struct rt_shader_s {
@@ -203,9 +238,19 @@ int finish(rt_ctx ctx) {
 }
 void launchHeld(rt_ctx ctx);
 // The dispatch stream, for everything except the merged launches themselves: what is held back goes first.
-hipStream_t S(rt_ctx ctx) {
+// SK: for the frame's own kernels and for calls that put nothing on the stream the next frame's primary rays could
+// conflict with.  S: anything else (marks the stream dirty, see rt_ctx_s::mainDirty).
+hipStream_t SK(rt_ctx ctx) {
     if (ctx->held.kind) launchHeld(ctx);
     return ctx->stream0;
+}
+hipStream_t S(rt_ctx ctx) {
+    ctx->mainDirty = true;
+    return SK(ctx);
+}
+void markAfterCandidates(rt_ctx ctx) {
+    if (!ctx->overlap || !ctx->behindCandidates || !ctx->evAfterCandidates) return;
+    ctx->afterCandidatesValid = hipEventRecord(ctx->evAfterCandidates, ctx->stream0) == hipSuccess;
 }
 
 Planes planesOf(rt_buffer b) {
@@ -612,7 +657,7 @@ int pixelGrid(rt_ctx ctx, KParams& P, int gx, int gy, unsigned* blocks, rt_ctx_s
         m.n = m.nDyn = (regions + 7) / 8 * (8 * RT_REGION * RT_REGION);
         m.dynValid = false; m.age = 0;
         HIP_TRY(ctx, hipMemsetAsync(m.cost, 0, (size_t)bx * by * 4 * sizeof(uint32_t), S(ctx)));
-        m.steps = nullptr; m.stepsValid = false; m.rankedBySteps = false; m.dynHits = nullptr;
+        m.steps = nullptr; m.stepsValid = false; m.rankedBySteps = false; m.dynHits = nullptr; m.pendingDyn = false; m.pendingMeasured = false;
         hipLaunchKernelGGL(k_order_blocks, dim3(1), dim3(1024), 0, S(ctx), m.cost, m.bx, m.by, m.dyn, m.nDyn, 0);
         LAUNCH_TRY(ctx, "order_blocks");
         P.blockMap = m.dev;
@@ -640,7 +685,7 @@ int pixelGrid(rt_ctx ctx, KParams& P, int gx, int gy, unsigned* blocks, rt_ctx_s
         ctx->blockMaps.erase(ctx->blockMaps.begin());
     }
     std::vector<uint32_t> map = buildBlockMap(bx, by, mode);
-    rt_ctx_s::BlockMap m = {(int)bx, (int)by, nullptr, (unsigned)map.size(), nullptr, nullptr, 0, false, 0, nullptr, false, false, nullptr};
+    rt_ctx_s::BlockMap m = {(int)bx, (int)by, nullptr, (unsigned)map.size(), nullptr, nullptr, 0, false, 0, nullptr, false, false, nullptr, false, false};
     HIP_TRY(ctx, hipMalloc((void**)&m.dev, map.size() * 4));
     HIP_TRY(ctx, hipMemcpy(m.dev, map.data(), map.size() * 4, hipMemcpyHostToDevice));
     const unsigned regions = ((bx + RT_REGION - 1) / RT_REGION) * ((by + RT_REGION - 1) / RT_REGION);
@@ -658,7 +703,10 @@ int pixelGrid(rt_ctx ctx, KParams& P, int gx, int gy, unsigned* blocks, rt_ctx_s
 }
 // After InitialTrace's primary-ray kernel: rank the regions by the hit counts it left and switch this grid to the
 // heaviest-first table (used by every later launch on the same grid, including the next frame's InitialTrace).
-void reorderBlocks(rt_ctx ctx, rt_ctx_s::BlockMap* m) {
+// `primaryOnStream1`: the primary rays that left the hit counts run on stream1, and so will the next ones: their own
+// table (dynHits) is rebuilt there, behind the launch that counted and ahead of the next one that reads it, and the
+// table of stream0's kernels on stream0, where it is called from once stream0 waits for the primary rays.
+void reorderBlocks(rt_ctx ctx, rt_ctx_s::BlockMap* m, bool primaryOnStream1) {
     if (!m || !m->dyn) return;
     // the ranking moves slowly from frame to frame: refresh it on the first frame and then every eighth (a stale
     // order is still a complete one; it only costs a little balance after a camera cut)
@@ -666,9 +714,16 @@ void reorderBlocks(rt_ctx ctx, rt_ctx_s::BlockMap* m) {
     const bool firstMeasured = measured && !m->rankedBySteps;   // the first frame after measurements exist re-ranks at once
     if (m->dynValid && !firstMeasured && (++m->age % 8) != 0) return;
     m->rankedBySteps = measured;
-    hipLaunchKernelGGL(k_order_blocks, dim3(1), dim3(1024), 0, S(ctx), measured ? m->steps : m->cost, m->bx, m->by, m->dyn, m->nDyn, measured ? 1 : 0);
     // the primary rays' cost follows the hit count, not the secondary rays' steps: their launch gets a ranking of its own
-    if (m->dynHits) hipLaunchKernelGGL(k_order_blocks, dim3(1), dim3(1024), 0, S(ctx), m->cost, m->bx, m->by, m->dynHits, m->nDyn, 0);
+    if (m->dynHits) hipLaunchKernelGGL(k_order_blocks, dim3(1), dim3(1024), 0, primaryOnStream1 ? ctx->stream1 : SK(ctx), m->cost, m->bx, m->by, m->dynHits, m->nDyn, 0);
+    m->pendingDyn = true;
+    m->pendingMeasured = measured;
+}
+// The second half, on stream0 after it has been made to wait for the primary rays.
+void reorderBlocksMain(rt_ctx ctx, rt_ctx_s::BlockMap* m) {
+    if (!m || !m->dyn || !m->pendingDyn) return;
+    m->pendingDyn = false;
+    hipLaunchKernelGGL(k_order_blocks, dim3(1), dim3(1024), 0, SK(ctx), m->pendingMeasured ? m->steps : m->cost, m->bx, m->by, m->dyn, m->nDyn, m->pendingMeasured ? 1 : 0);
     m->dynValid = true;
 }
 
@@ -678,7 +733,7 @@ struct LaunchScope {
     int ik;
     hipEvent_t start = nullptr, stop = nullptr;
     hipStream_t stream;
-    LaunchScope(rt_ctx c, int k, KParams* P) : ctx(c), ik(k), stream(S(c)) {
+    LaunchScope(rt_ctx c, int k, KParams* P, hipStream_t on = nullptr) : ctx(c), ik(k), stream(on ? on : SK(c)) {
         if (P) { P->stats = ctx->statsLevel > 0 ? ctx->statsDev + (size_t)k * STAT_SHARDS * 8 : nullptr; P->statsLevel = ctx->statsLevel; }
         ctx->launches[k]++;
         if (!ctx->timing || ctx->noAlloc || (ctx->timingOnly >= 0 && ctx->timingOnly != k)) return;
@@ -713,6 +768,45 @@ int drainTiming(rt_ctx ctx) {
     return RT_OK;
 }
 
+// Prepares a dispatch whose primary rays run on stream1 beside what stream0 holds (see rt_ctx_s::stream1): makes the
+// second copy of every object in `flips` the current one, and orders stream1 behind the last readers of those copies.
+// Returns false (nothing changed) when that cannot be done; the caller then launches on stream0 as usual.
+struct Flip { void** dev; void** alt; size_t bytes; };
+bool beginOverlappedPrimary(rt_ctx ctx, const Flip* flips, int n) {
+    if (!ctx->stream1 || !ctx->evReaders[0] || !ctx->evReaders[1] || !ctx->evPrimary) return false;
+    for (int i = 0; i < n; i++) {
+        if (*flips[i].alt) continue;
+        if (hipMalloc(flips[i].alt, flips[i].bytes) != hipSuccess) { *flips[i].alt = nullptr; return false; }
+        // (rows a banded launch never writes must not hold garbage a readback could return)
+        if (hipMemsetAsync(*flips[i].alt, 0, flips[i].bytes, S(ctx)) != hipSuccess) return false;
+    }
+    // everything enqueued so far reads (at most) the copies that are current now
+    const int k = ctx->ring;
+    if (hipEventRecord(ctx->evReaders[k], ctx->stream0) != hipSuccess) return false;
+    ctx->readersValid[k] = true;
+    if (ctx->mainDirty) {  // something else went onto stream0: behind all of it, once
+        if (hipStreamWaitEvent(ctx->stream1, ctx->evReaders[k], 0) != hipSuccess) return false;
+        ctx->mainDirty = false;
+    } else if (ctx->readersValid[k ^ 1]) {  // the copies written now were current until the dispatch before this one
+        if (hipStreamWaitEvent(ctx->stream1, ctx->evReaders[k ^ 1], 0) != hipSuccess) return false;
+    }
+    if (ctx->behindCandidates && ctx->afterCandidatesValid && hipStreamWaitEvent(ctx->stream1, ctx->evAfterCandidates, 0) != hipSuccess) return false;
+    ctx->ring = k ^ 1;
+    for (int i = 0; i < n; i++) std::swap(*flips[i].dev, *flips[i].alt);
+    return true;
+}
+// After the overlapped launch: stream0 goes on only when the primary rays are done.
+int endOverlappedPrimary(rt_ctx ctx) {
+    HIP_TRY(ctx, hipEventRecord(ctx->evPrimary, ctx->stream1));
+    HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream0, ctx->evPrimary, 0));
+    return RT_OK;
+}
+bool mayOverlap(rt_ctx ctx, bool instr, const KParams& P) {
+    if (!ctx->overlap || !ctx->fuse || ctx->noAlloc || instr || ctx->statsLevel >= 2) return false;
+    const bool wholeImage = P.row0 <= 0 && P.row1 >= P.ResY;
+    return wholeImage || ctx->overlap == 2;
+}
+
 // Launches what is held back (rt_ctx_s::Deferred), as it was dispatched.  `acc` = the dispatch that follows is merged into
 // it (AccumulateFrames into a held TraceRays, TemporalReuse into a held candidate kernel): the caller has put what that
 // dispatch binds into the held parameters.
@@ -729,6 +823,7 @@ void launchHeld(rt_ctx ctx, bool acc) {
         LaunchScope ls(ctx, IK_CANDIDATES, &h.P);
         if (acc) hipLaunchKernelGGL((k_candidates<false, true>), dim3(h.blocks), dim3(256), h.ldsBytes, ctx->stream0, h.P);
         else hipLaunchKernelGGL((k_candidates<false, false>), dim3(h.blocks), dim3(256), h.ldsBytes, ctx->stream0, h.P);
+        markAfterCandidates(ctx);
     } else if (h.kind == 4) {
         LaunchScope ls(ctx, IK_RIS_TRACE_RAYS, &h.P);
         if (acc) hipLaunchKernelGGL((k_ris_trace_rays<false, true>), dim3(h.blocks), dim3(256), h.ldsBytes, ctx->stream0, h.P);
@@ -792,27 +887,52 @@ int dispatchReSTIR(rt_shader sh, int kernel, int gx, int gy) {
             optionalTex(sh, kernel, "TextureAtlas", P.atlas);
             if (!blocks) break;
             size_t ldsBytes = (size_t)WAVES_PER_BLOCK * P.stackDepth * 64 * 4;
+            bool beside = false;
             {
                 if (grid) P.blockCost = grid->cost;
                 if (grid && grid->dynValid && grid->dynHits) { P.blockMap = grid->dynHits; blocks = grid->nDyn; }
-                LaunchScope ls(ctx, IK_PRIMARY, &P);
-                if (instr) hipLaunchKernelGGL(k_primary<true>, dim3(blocks), dim3(256), ldsBytes, S(ctx), P);
-                else hipLaunchKernelGGL(k_primary<false>, dim3(blocks), dim3(256), ldsBytes, S(ctx), P);
+                // beside the kernels stream0 still holds of the frames before, when nothing forbids it (rt_ctx_s::stream1)
+                rt_buffer bHit = boundBuffer(sh, kernel, "HitInfos");
+                rt_texture tDepth = boundTexture(sh, kernel, "DepthBuffer");
+                rt_texture tPoints = boundTexture(sh, kernel, P.FrameCount % 2 == 0 ? "RayHitPointsA" : "RayHitPointsB");
+                SK(ctx);   // (what is held goes first: it was dispatched before this)
+                const Flip flips[3] = {{&bHit->dev, &bHit->alt, layoutBytes(bHit, bHit->layout)}, {&tDepth->dev, &tDepth->alt, tDepth->bytes},
+                                       {&tPoints->dev, &tPoints->alt, tPoints->bytes}};
+                beside = mayOverlap(ctx, instr, P) && beginOverlappedPrimary(ctx, flips, 3);
+                if (beside) {
+                    P.hit = planesOf(bHit);
+                    P.depth.r = (float*)tDepth->dev;
+                    (P.FrameCount % 2 == 0 ? P.hitA : P.hitB).rgba = (float4*)tPoints->dev;
+                }
+                const bool background = beside && ctx->bgGroups > 0 && ctx->bgCounter && blocks > (unsigned)ctx->bgGroups &&
+                                        hipMemsetAsync(ctx->bgCounter, 0, 8 * sizeof(uint32_t), ctx->stream1) == hipSuccess;
+                {
+                    LaunchScope ls(ctx, IK_PRIMARY, &P, beside ? ctx->stream1 : nullptr);
+                    if (background) {
+                        P.bgCounter = ctx->bgCounter; P.bgBlocks = blocks;
+                        hipLaunchKernelGGL((k_primary<false, true>), dim3((unsigned)ctx->bgGroups), dim3(256), ldsBytes, ls.stream, P);
+                    } else if (instr) hipLaunchKernelGGL(k_primary<true>, dim3(blocks), dim3(256), ldsBytes, ls.stream, P);
+                    else hipLaunchKernelGGL(k_primary<false>, dim3(blocks), dim3(256), ldsBytes, ls.stream, P);
+                }
+                if (!beside) ctx->mainDirty = true;   // primary rays on stream0: the next overlapped ones follow them
             }
+            if (grid && grid->dyn) reorderBlocks(ctx, grid, beside);   // (the primary rays' own table: behind them, on their stream)
+            if (beside && (rc = endOverlappedPrimary(ctx))) return rc;
+            reorderBlocksMain(ctx, grid);
             if (grid && grid->dyn) {  // the candidate kernel and everything after it run heaviest regions first
-                reorderBlocks(ctx, grid);
                 P.blockMap = grid->dyn;
                 blocks = grid->nDyn;
                 P.blockCost = nullptr;
             }
             if (mayHold(ctx, instr)) {  // held: a TemporalReuse that follows becomes part of the launch
-                S(ctx);
+                SK(ctx);
                 ctx->held.kind = 3; ctx->held.P = P; ctx->held.blocks = blocks; ctx->held.ldsBytes = ldsBytes; ctx->held.grid = grid;
                 ctx->held.withTransfer = false;
             } else {
                 LaunchScope ls(ctx, IK_CANDIDATES, &P);
-                if (instr) hipLaunchKernelGGL((k_candidates<true>), dim3(blocks), dim3(256), ldsBytes, S(ctx), P);
-                else hipLaunchKernelGGL((k_candidates<false>), dim3(blocks), dim3(256), ldsBytes, S(ctx), P);
+                if (instr) hipLaunchKernelGGL((k_candidates<true>), dim3(blocks), dim3(256), ldsBytes, ls.stream, P);
+                else hipLaunchKernelGGL((k_candidates<false>), dim3(blocks), dim3(256), ldsBytes, ls.stream, P);
+                markAfterCandidates(ctx);
             }
             break;
         }
@@ -821,7 +941,7 @@ int dispatchReSTIR(rt_shader sh, int kernel, int gx, int gy) {
             if ((rc = needRecs(sh, kernel, "CandidatesB", P.candB)) || (rc = checkCount(P.candB, "CandidatesB"))) return rc;
             if ((rc = needTex(sh, kernel, "DepthBuffer", true, X, Y, P.depth))) return rc;
             if (!blocks) break;
-            { LaunchScope ls(ctx, IK_SPATIAL, &P); hipLaunchKernelGGL(k_spatial, dim3(blocks), dim3(256), 0, S(ctx), P); }
+            { LaunchScope ls(ctx, IK_SPATIAL, &P); hipLaunchKernelGGL(k_spatial, dim3(blocks), dim3(256), 0, ls.stream, P); }
             break;
         }
         case 2: {  // TransferToOriginal
@@ -830,11 +950,11 @@ int dispatchReSTIR(rt_shader sh, int kernel, int gx, int gy) {
             if ((rc = needTex(sh, kernel, "DepthBuffer", true, X, Y, P.depth))) return rc;
             if (!blocks) break;
             if (mayHold(ctx, instr)) {  // held: a TraceRays that follows takes the copy along
-                S(ctx);
+                SK(ctx);
                 ctx->held.kind = 1; ctx->held.P = P; ctx->held.blocks = blocks; ctx->held.grid = grid; ctx->held.withTransfer = false;
             } else {
                 LaunchScope ls(ctx, IK_TRANSFER, &P);
-                hipLaunchKernelGGL(k_transfer, dim3(blocks), dim3(256), 0, S(ctx), P);
+                hipLaunchKernelGGL(k_transfer, dim3(blocks), dim3(256), 0, ls.stream, P);
             }
             break;
         }
@@ -857,7 +977,7 @@ int dispatchReSTIR(rt_shader sh, int kernel, int gx, int gy) {
                     break;
                 }
             }
-            { LaunchScope ls(ctx, IK_TEMPORAL, &P); hipLaunchKernelGGL(k_temporal, dim3(blocks), dim3(256), 0, S(ctx), P); }
+            { LaunchScope ls(ctx, IK_TEMPORAL, &P); hipLaunchKernelGGL(k_temporal, dim3(blocks), dim3(256), 0, ls.stream, P); }
             break;
         }
         case 4: {  // TraceRays
@@ -878,13 +998,13 @@ int dispatchReSTIR(rt_shader sh, int kernel, int gx, int gy) {
                                       h.P.cand.count == P.cand.count && h.P.candB.count >= P.cand.count && h.P.row0 == P.row0 && h.P.row1 == P.row1 &&
                                       h.P.ResX == P.ResX && h.P.ResY == P.ResY;
                 if (takeCopy) { P.candB = h.P.candB; P.depth = h.P.depth; ctx->held.kind = 0; }
-                else S(ctx);
+                else SK(ctx);
                 ctx->held.kind = 2; ctx->held.P = P; ctx->held.blocks = blocks; ctx->held.ldsBytes = ldsBytes; ctx->held.grid = grid;
                 ctx->held.withTransfer = takeCopy;
             } else {
                 LaunchScope ls(ctx, IK_TRACE_RAYS, &P);
-                if (instr) hipLaunchKernelGGL((k_trace_rays<true>), dim3(blocks), dim3(256), ldsBytes, S(ctx), P);
-                else hipLaunchKernelGGL((k_trace_rays<false>), dim3(blocks), dim3(256), ldsBytes, S(ctx), P);
+                if (instr) hipLaunchKernelGGL((k_trace_rays<true>), dim3(blocks), dim3(256), ldsBytes, ls.stream, P);
+                else hipLaunchKernelGGL((k_trace_rays<false>), dim3(blocks), dim3(256), ldsBytes, ls.stream, P);
             }
             break;
         }
@@ -949,33 +1069,47 @@ int dispatchRIS(rt_shader sh, int kernel, int gx, int gy) {
         if ((rc = needTex(sh, kernel, "DebugOverlay", false, X, Y, P.debugOverlay))) return rc;
         if ((rc = needTex(sh, kernel, "RayHitPoints", false, X, Y, P.rayHitPoints))) return rc;
         if (!blocks) return RT_OK;
+        bool beside = false;
         {
             if (grid) P.blockCost = grid->cost;
-            LaunchScope ls(ctx, IK_RIS_PRIMARY, &P);
-            if (instr) hipLaunchKernelGGL(k_ris_primary<true>, dim3(blocks), dim3(256), ldsBytes, S(ctx), P);
-            else hipLaunchKernelGGL(k_ris_primary<false>, dim3(blocks), dim3(256), ldsBytes, S(ctx), P);
+            // beside the kernels stream0 still holds of the frames before (rt_ctx_s::stream1): the RIS project's primary rays
+            // overwrite nothing but HitInfos that those still read
+            SK(ctx);
+            const Flip flips[1] = {{&hit->dev, &hit->alt, hit->bytes}};
+            beside = mayOverlap(ctx, instr, P) && beginOverlappedPrimary(ctx, flips, 1);
+            if (beside) P.risHit = (rt_ris_hit_info*)hit->dev;
+            {
+                LaunchScope ls(ctx, IK_RIS_PRIMARY, &P, beside ? ctx->stream1 : nullptr);
+                if (instr) hipLaunchKernelGGL(k_ris_primary<true>, dim3(blocks), dim3(256), ldsBytes, ls.stream, P);
+                else hipLaunchKernelGGL(k_ris_primary<false>, dim3(blocks), dim3(256), ldsBytes, ls.stream, P);
+            }
+            if (!beside) ctx->mainDirty = true;   // primary rays on stream0: the next overlapped ones follow them
         }
+        if (grid && grid->dyn) reorderBlocks(ctx, grid, beside);
+        if (beside && (rc = endOverlappedPrimary(ctx))) return rc;
+        reorderBlocksMain(ctx, grid);
         if (grid && grid->dyn) {
-            reorderBlocks(ctx, grid);
             P.blockMap = grid->dyn;
             blocks = grid->nDyn;
             P.blockCost = nullptr;
         }
         {
             LaunchScope ls(ctx, IK_RIS_CANDIDATES, &P);
-            hipLaunchKernelGGL(k_ris_candidates, dim3(blocks), dim3(256), 0, S(ctx), P);
+            hipLaunchKernelGGL(k_ris_candidates, dim3(blocks), dim3(256), 0, ls.stream, P);
+            // (no markAfterCandidates: the RIS project's primary rays do best beside the whole of the frame before,
+            // 0.756 against 0.784 ms per 1080p frame)
         }
     } else {
         if ((rc = needTex(sh, kernel, "Result", false, X, Y, P.result))) return rc;
         if (!blocks) return RT_OK;
         if (mayHold(ctx, instr)) {  // held: an AccumulateFrames that follows becomes part of the launch
-            S(ctx);
+            SK(ctx);
             ctx->held.kind = 4; ctx->held.P = P; ctx->held.blocks = blocks; ctx->held.ldsBytes = ldsBytes; ctx->held.grid = grid;
             ctx->held.withTransfer = false;
         } else {
             LaunchScope ls(ctx, IK_RIS_TRACE_RAYS, &P);
-            if (instr) hipLaunchKernelGGL((k_ris_trace_rays<true>), dim3(blocks), dim3(256), ldsBytes, S(ctx), P);
-            else hipLaunchKernelGGL((k_ris_trace_rays<false>), dim3(blocks), dim3(256), ldsBytes, S(ctx), P);
+            if (instr) hipLaunchKernelGGL((k_ris_trace_rays<true>), dim3(blocks), dim3(256), ldsBytes, ls.stream, P);
+            else hipLaunchKernelGGL((k_ris_trace_rays<false>), dim3(blocks), dim3(256), ldsBytes, ls.stream, P);
         }
     }
     return finish(ctx);
@@ -1049,7 +1183,7 @@ int dispatchPostProc(rt_shader sh, int kernel, int gx, int gy) {
             return finish(ctx);
         }
     }
-    if (blocks) { LaunchScope ls(ctx, IK_ACCUMULATE, &P); hipLaunchKernelGGL(k_accumulate, dim3(blocks), dim3(256), 0, S(ctx), P); }
+    if (blocks) { LaunchScope ls(ctx, IK_ACCUMULATE, &P); hipLaunchKernelGGL(k_accumulate, dim3(blocks), dim3(256), 0, ls.stream, P); }
     return finish(ctx);
 }
 
@@ -1077,6 +1211,28 @@ int rt_create(int device_id, rt_ctx* out) {
         delete ctx;
         return RT_ERR_NO_DEVICE;
     }
+    {   // the stream of the overlapped primary rays.  Default priority: a lowest-priority stream measured no better
+        // (0.752 against 0.745 ms per 1080p frame), and in a process in which RCCL had created a communicator a wait
+        // of stream0 on an event of a lowest-priority stream never returned (RT_OVERLAP_PRIORITY=1 selects it anyway).
+        static const int overlap = [] { const char* e = getenv("RT_OVERLAP"); return e ? atoi(e) : 1; }();
+        ctx->overlap = overlap < 0 || overlap > 2 ? 1 : overlap;
+        static const bool behindCand = [] { const char* e = getenv("RT_OVERLAP_START"); return e ? atoi(e) != 0 : true; }();
+        ctx->behindCandidates = behindCand;
+        static const int bg = [] { const char* e = getenv("RT_PRIMARY_BG"); return e ? atoi(e) : 0; }();
+        ctx->bgGroups = bg < 0 ? 0 : (bg + 7) / 8 * 8;
+        if (hipMalloc((void**)&ctx->bgCounter, 8 * sizeof(uint32_t)) != hipSuccess) ctx->bgCounter = nullptr;
+        int least = 0, greatest = 0;
+        static const bool lowPriority = [] { const char* e = getenv("RT_OVERLAP_PRIORITY"); return e ? atoi(e) != 0 : false; }();
+        if (!lowPriority || hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) least = 0;
+        if (hipStreamCreateWithPriority(&ctx->stream1, hipStreamNonBlocking, least) != hipSuccess ||
+            hipEventCreateWithFlags(&ctx->evReaders[0], hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&ctx->evReaders[1], hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&ctx->evAfterCandidates, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&ctx->evPrimary, hipEventDisableTiming) != hipSuccess) {
+            rt_destroy(ctx);
+            return RT_ERR_NO_DEVICE;
+        }
+    }
     // this device's copy of the file-scope scratch array (every GPU has its own, at its own address)
     if (hipGetSymbolAddress((void**)&ctx->scratch, HIP_SYMBOL(scratch)) != hipSuccess || !ctx->scratch) {
         rt_destroy(ctx);
@@ -1100,6 +1256,7 @@ void rt_destroy(rt_ctx ctx) {
         if (pr.objRoot) e = hipFree(pr.objRoot);
     }
     if (ctx->statsDev) e = hipFree(ctx->statsDev);
+    if (ctx->bgCounter) e = hipFree(ctx->bgCounter);
     for (rt_shader sh : ctx->shaders) sh->ctx = nullptr;   // a shader closed after its context only frees itself
     if (ctx->noAllocDone) e = hipEventDestroy(ctx->noAllocDone);
     for (auto& m : ctx->blockMaps) { e = hipFree(m.dev); if (m.dyn) e = hipFree(m.dyn); if (m.cost) e = hipFree(m.cost); if (m.steps) e = hipFree(m.steps); if (m.dynHits) e = hipFree(m.dynHits); }
@@ -1108,6 +1265,8 @@ void rt_destroy(rt_ctx ctx) {
     for (auto ev : ctx->orderEvent) if (ev) e = hipEventDestroy(ev);
     for (auto ev : ctx->marks) if (ev) e = hipEventDestroy(ev);
     if (ctx->transferStream) { e = hipStreamSynchronize(ctx->transferStream); e = hipStreamDestroy(ctx->transferStream); }
+    if (ctx->stream1) { e = hipStreamSynchronize(ctx->stream1); e = hipStreamDestroy(ctx->stream1); }
+    for (hipEvent_t ev : {ctx->evReaders[0], ctx->evReaders[1], ctx->evPrimary, ctx->evAfterCandidates}) if (ev) e = hipEventDestroy(ev);
     e = hipStreamDestroy(ctx->stream0);
     (void)e;
     delete ctx;
@@ -1115,7 +1274,7 @@ void rt_destroy(rt_ctx ctx) {
 
 int rt_sync(rt_ctx ctx) {
     if (!ctx) return RT_ERR_INVALID_ARG;
-    HIP_TRY(ctx, hipStreamSynchronize(S(ctx)));
+    HIP_TRY(ctx, hipStreamSynchronize(SK(ctx)));   // (includes the overlapped primary rays: stream0 waits for them)
     if (ctx->transferStream) HIP_TRY(ctx, hipStreamSynchronize(ctx->transferStream));
     return finish(ctx);
 }
@@ -1137,7 +1296,7 @@ int rt_stream_order(rt_ctx ctx, int first) {
     if (!rt_transfer_stream(ctx)) return RT_ERR_NO_DEVICE;
     hipEvent_t& ev = ctx->orderEvent[first];
     if (!ev) HIP_TRY(ctx, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
-    hipStream_t from = first == 0 ? S(ctx) : ctx->transferStream, to = first == 0 ? ctx->transferStream : S(ctx);
+    hipStream_t from = first == 0 ? SK(ctx) : ctx->transferStream, to = first == 0 ? ctx->transferStream : SK(ctx);
     HIP_TRY(ctx, hipEventRecord(ev, from));
     HIP_TRY(ctx, hipStreamWaitEvent(to, ev, 0));
     return finish(ctx);
@@ -1148,7 +1307,7 @@ int rt_mark(rt_ctx ctx, int stream, int slot) {
     if (rc) return rc;
     if (stream == 1 && !rt_transfer_stream(ctx)) return RT_ERR_NO_DEVICE;
     if (!ctx->marks[slot]) HIP_TRY(ctx, hipEventCreate(&ctx->marks[slot]));
-    HIP_TRY(ctx, hipEventRecord(ctx->marks[slot], stream == 0 ? S(ctx) : ctx->transferStream));
+    HIP_TRY(ctx, hipEventRecord(ctx->marks[slot], stream == 0 ? SK(ctx) : ctx->transferStream));
     return finish(ctx);
 }
 int rt_mark_elapsed(rt_ctx ctx, int a, int b, double* ms) {
@@ -1169,7 +1328,17 @@ int rt_flush(rt_ctx ctx) {
     if (!ctx) return RT_ERR_INVALID_ARG;
     int rc = useDevice(ctx);
     if (rc) return rc;
-    S(ctx);
+    SK(ctx);
+    return finish(ctx);
+}
+int rt_set_overlap(rt_ctx ctx, int mode) {
+    if (!ctx || mode < 0 || mode > 2) return RT_ERR_INVALID_ARG;
+    int rc = useDevice(ctx);
+    if (rc) return rc;
+    SK(ctx);
+    ctx->overlap = mode;
+    ctx->afterCandidatesValid = false;
+    ctx->mainDirty = true;   // the next overlapped primary rays follow all of stream0
     return finish(ctx);
 }
 int rt_set_fusion(rt_ctx ctx, int enabled) {
@@ -1415,6 +1584,7 @@ void rt_buffer_release(rt_buffer b) {
         pr = rt_ctx_s::Prep();
     }
     if (b->dev) e = hipFree(b->dev);
+    if (b->alt) e = hipFree(b->alt);
     (void)e;
     delete b;
 }
@@ -1506,6 +1676,7 @@ void rt_texture_release(rt_texture t) {
         for (auto& table : sh->textures)
             for (auto it = table.begin(); it != table.end();) it = it->second == t ? table.erase(it) : std::next(it);
     if (t->dev) e = hipFree(t->dev);
+    if (t->alt) e = hipFree(t->alt);
     (void)e;
     delete t;
 }
@@ -1515,7 +1686,7 @@ int rt_buffer_map_rows(rt_buffer b, int width, int row0, int row1, rt_segment ou
     rt_ctx ctx = b->ctx;
     if (width < 1 || row0 < 0 || row1 < row0 || (int64_t)row1 * width > b->count)
         return fail(ctx, RT_ERR_INVALID_ARG, "rows [%d,%d) of width %d are outside the buffer", row0, row1, width);
-    S(ctx);   // whoever reads through these pointers orders itself against the stream: nothing may still be held back
+    SK(ctx);   // whoever reads through these pointers orders itself against the stream: nothing may still be held back
     const size_t first = (size_t)row0 * width, n = (size_t)(row1 - row0) * width;
     char* base = (char*)b->dev;
     if (b->layout == LAYOUT_AOS) {
@@ -1534,7 +1705,7 @@ int rt_buffer_map_rows(rt_buffer b, int width, int row0, int row1, rt_segment ou
 int rt_texture_map_rows(rt_texture t, int row0, int row1, rt_segment* out) {
     if (!t || !out) return RT_ERR_INVALID_ARG;
     if (row0 < 0 || row1 < row0 || row1 > t->h) return fail(t->ctx, RT_ERR_INVALID_ARG, "rows [%d,%d) are outside the texture", row0, row1);
-    S(t->ctx);
+    SK(t->ctx);
     const size_t texel = t->format == RT_FORMAT_R32F ? 4 : 16;
     out->ptr = (char*)t->dev + (size_t)row0 * t->w * texel;
     out->bytes = (size_t)(row1 - row0) * t->w * texel;
