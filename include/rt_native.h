@@ -91,6 +91,16 @@ int rt_flush(rt_ctx ctx);
  * after the other.  Device pointers from rt_buffer_map_rows / rt_texture_map_rows of those four objects are valid until
  * the next such dispatch.  No counterpart in the reference. */
 int rt_set_overlap(rt_ctx ctx, int mode);
+/* Implementation choices that change speed only, never results; each also has an environment variable that sets the
+ * default of new contexts.  Kept so that the alternatives that were measured and not adopted stay testable:
+ *   "spatial_lds_max_offset"     (RT_SPATIAL_LDS, default 0)   SpatialReusePass stages the neighbourhood of each 16x16
+ *                                 block in LDS when MaxOffset is at most this (0: every lane gathers for itself)
+ *   "primary_background_groups"  (RT_PRIMARY_BG, default 0)    overlapped primary rays as this many resident workgroups
+ *                                 that walk the block table (0: one workgroup per block)
+ *   "overlap_behind_candidates"  (RT_OVERLAP_START, default 1) overlapped primary rays of the ReSTIR project start only
+ *                                 after the previous frame's candidate kernel (0: as early as their inputs allow)
+ * Unknown names fail with RT_ERR_INVALID_ARG.  No counterpart in the reference. */
+int rt_set_tuning(rt_ctx ctx, const char* name, int value);
 /* enabled = 0: every dispatch is launched by the call that makes it (nothing is held or merged); 1 (the default
  * unless RT_FUSE=0 is in the environment): consecutive dispatches that can run as one launch do.  Results are
  * bit-identical either way.  No counterpart in the reference. */

@@ -32,6 +32,7 @@ internal static class RtNative
     [DllImport(Lib)] public static extern int rt_flush(IntPtr ctx);
     [DllImport(Lib)] public static extern int rt_set_fusion(IntPtr ctx, int enabled);
     [DllImport(Lib)] public static extern int rt_set_overlap(IntPtr ctx, int mode);
+    [DllImport(Lib)] public static extern int rt_set_tuning(IntPtr ctx, string name, int value);
     [DllImport(Lib)] public static extern int rt_set_row_band(IntPtr ctx, int row0, int row1);
 
     // shaders

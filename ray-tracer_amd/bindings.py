@@ -64,7 +64,7 @@ def native_lib():
         sig = {
             "rt_create": (ci, [ci, C.POINTER(vp)]), "rt_destroy": (None, [vp]), "rt_sync": (ci, [vp]),
             "rt_last_error": (cs, [vp]), "rt_stream": (vp, [vp]), "rt_transfer_stream": (vp, [vp]),
-            "rt_flush": (ci, [vp]), "rt_set_fusion": (ci, [vp, ci]), "rt_set_overlap": (ci, [vp, ci]),
+            "rt_flush": (ci, [vp]), "rt_set_fusion": (ci, [vp, ci]), "rt_set_overlap": (ci, [vp, ci]), "rt_set_tuning": (ci, [vp, cs, ci]),
             "rt_stream_order": (ci, [vp, ci]), "rt_mark": (ci, [vp, ci, ci]), "rt_mark_elapsed": (ci, [vp, ci, ci, C.POINTER(C.c_double)]), "rt_set_row_band": (ci, [vp, ci, ci]),
             "rt_shader_open": (ci, [vp, cs, C.POINTER(vp)]), "rt_shader_close": (None, [vp]),
             "rt_find_kernel": (ci, [vp, cs]), "rt_dispatch": (ci, [vp, ci, ci, ci, ci]),
@@ -430,6 +430,10 @@ class RtContext:
 
     def set_fusion(self, enabled):
         self.check(self.lib.rt_set_fusion(self.h, 1 if enabled else 0), "rt_set_fusion")
+
+    def set_tuning(self, name, value):
+        """Speed-only implementation choices (see rt_set_tuning in include/rt_native.h)."""
+        self.check(self.lib.rt_set_tuning(self.h, name.encode(), int(value)), f"rt_set_tuning({name})")
 
     def set_overlap(self, mode):
         """0: off; 1: the next frame's primary rays run beside the previous frame's last kernels (whole-image

@@ -1050,6 +1050,103 @@ __global__ __launch_bounds__(256) void k_spatial(const KParams P) {
     if (P.stats && P.statsLevel >= 2) { waveAdd(P.stats + ST_ACTIVE, active ? 1u : 0u); waveAdd(P.stats + ST_NEIGHBOURS, neighbours); }
 }
 
+// SpatialReusePass for small windows, with the neighbourhood staged in LDS.  The nine neighbours of a pixel lie within
+// MaxOffset pixels of it, so everything the 256 pixels of a workgroup's 16x16 block can ask for is the (16 + 2 MaxOffset)^2
+// region around the block: 484 records for the first pass (MaxOffset 3) against the 2,560 record fetches the block makes
+// when every lane gathers for itself.  The workgroup loads the region's depths, then - in coalesced runs of whole region
+// rows, four lanes per 64-byte record - the records of its hit pixels (a neighbour whose depth holds no hit is rejected
+// before its reservoir is looked at, RS:531), as four planes of 16-byte quarters, and every lane then takes its
+// neighbours from LDS.  The coordinates the reference does NOT reject (RS:528 is always false) - a negative x, which
+// wraps into the previous image row, or a negative y - never fall into the region's in-image part and keep the global
+// path of k_spatial.  Same draws, same tests, same arithmetic in the same order: bit-identical to k_spatial.
+// LDS: 68 bytes per region pixel (33 KB at MaxOffset 3, 79 KB at MaxOffset 9); the region's LDS is reused for the
+// transposed store of the block's own results.
+DEV Reservoir spatialNeighbourGlobal(const KParams& P, const Recs& src, int offX, int offY, uint32_t pixelBaseIndex, bool inImage,
+                                     float& nDepth, bool& inBuffer) {
+    const uint32_t pixelIndex = (uint32_t)P.ResX * (uint32_t)offY + (uint32_t)offX;
+    inBuffer = (int64_t)pixelIndex < src.count;  // index beyond the buffer -> zero reservoir
+    const int64_t li = inImage && inBuffer ? (int64_t)pixelIndex : (int64_t)pixelBaseIndex;
+    nDepth = depthAt(P, offX, offY);
+    const float4* cq = src.q + li * 4;
+    return unpackReservoir(cq[0], cq[1], cq[2], cq[3]);
+}
+__global__ __launch_bounds__(256) void k_spatial_lds(const KParams P) {
+    extern __shared__ float4 region[];
+    const int M = P.MaxOffset, RW = 16 + 2 * M, RN = RW * RW;
+    float* rdepth = (float*)(region + 4 * RN);
+    const uint32_t m = P.blockMap[blockIdx.x];
+    if (m == 0xffffffffu) return;   // (the whole workgroup)
+    const int tid = (int)threadIdx.x;
+    const int rx0 = (int)(m & 0xffffu) * 16 - M, ry0 = (P.row0 & ~7) + (int)(m >> 16) * 16 - M;
+    const Recs& src = P.ReuseBufferCycle ? P.cand : P.candB;
+    const Recs& dstb = P.ReuseBufferCycle ? P.candB : P.cand;
+    const Pixel px = pixelOfThread(P);
+    const int own = (px.y - ry0) * RW + (px.x - rx0);
+    const bool active = px.active && depthAt(P, px.x, px.y) != INF();
+    if (!__syncthreads_or(active ? 1 : 0)) return;   // no hit pixel in the block
+    // depths and records of the region in one go (a region row is one run of RW * 64 contiguous bytes); the records of
+    // pixels without a hit are loaded too: nothing reads them, and waiting for the depths first costs a round trip
+    for (int row = tid >> 6; row < RW; row += 4) {
+        const int y = ry0 + row;
+        for (int col = tid & 63; col < RW; col += 64) rdepth[row * RW + col] = depthAt(P, rx0 + col, y);
+        if (y < 0 || y >= P.ResY) continue;
+        const float4* rowBase = src.q + ((int64_t)y * P.ResX + rx0) * 4;
+        for (int j = tid & 63; j < RW * 4; j += 64) {
+            const int col = j >> 2, q = j & 3, x = rx0 + col;
+            if (x >= 0 && x < P.ResX) region[q * RN + row * RW + col] = rowBase[j];
+        }
+    }
+    __syncthreads();
+    uint32_t neighbours = 0;
+    Reservoir sp = emptyReservoir();
+    if (active) {
+        sp = unpackReservoir(region[own], region[RN + own], region[2 * RN + own], region[3 * RN + own]);
+        const uint32_t idx = (uint32_t)px.x, idy = (uint32_t)px.y;
+        uint32_t state = idy * (uint32_t)P.ResX + idx + P.FrameRand;
+        const uint32_t pixelBaseIndex = (uint32_t)P.ResX * idy + idx;
+        const Reservoir base = sp;
+        for (uint32_t k = 0; k < P.TemporalCandidatesNum; k++) {
+            int ox = rtdm::f2i((float)randIntSpan(-P.MaxOffset, P.MaxOffset, state));
+            int oy = rtdm::f2i((float)randIntSpan(-P.MaxOffset, P.MaxOffset, state));
+            int offX = px.x + ox, offY = px.y + oy;
+            const bool inImage = !(offX >= P.ResX || offY >= P.ResY);
+            Reservoir cand;
+            if (inImage && offX >= 0 && offY >= 0 && ox >= -M && ox <= M && oy >= -M && oy <= M) {
+                const int li = (offY - ry0) * RW + (offX - rx0);
+                if (rdepth[li] == INF()) continue;
+                cand = unpackReservoir(region[li], region[RN + li], region[2 * RN + li], region[3 * RN + li]);
+            } else {   // outside the image, or one of the coordinates the reference lets through (see k_spatial)
+                float nDepth;
+                bool inBuffer;
+                cand = spatialNeighbourGlobal(P, src, offX, offY, pixelBaseIndex, inImage, nDepth, inBuffer);
+                if (!inImage || nDepth == INF()) continue;
+                if (!inBuffer) cand = emptyReservoir();
+            }
+            neighbours++;
+            if (cand.dir.x == 0 || cand.dir.y == 0 || cand.dir.z == 0) continue;  // `all(dir) == 0`, RS:536
+            float hitPointDiff = length(base.hitPoint - cand.hitPoint);
+            float normalDiffDeg = P.SpatialNormalsAngleThreshold > 181.0f ? 0.0f : angleBetweenNormals(base.normal, cand.normal);
+            if (hitPointDiff > P.SpatialHitPointDiffThreshold || normalDiffDeg > P.SpatialNormalsAngleThreshold ||
+                rtdm::fabs_(sp.brdf - cand.brdf) > P.SpatialBRDFThreshold)
+                continue;
+            if (weightedRand(cand.chosenWeight, sp.totWeights, state)) {
+                sp.dir = cand.dir; sp.chosenWeight = cand.chosenWeight; sp.hitPoint = cand.hitPoint;
+                sp.normal = cand.normal; sp.brdf = cand.brdf;
+            }
+            sp.totWeights += cand.totWeights;
+            sp.totCandidates += cand.totCandidates;
+        }
+    }
+    __syncthreads();   // every lane is done with the region: its LDS now stages the stores
+    const unsigned long long mask = __builtin_amdgcn_ballot_w64(active);
+    if (mask != 0) {
+        float4* stage = region + (threadIdx.x >> 6) * 64 * COOP_ROW;
+        const int x0 = px.x - (int)(threadIdx.x & 7), y0 = px.y - (int)((threadIdx.x & 63) >> 3);
+        coopStoreReservoir(P, dstb, x0, y0, mask, stage, sp);
+    }
+    if (P.stats && P.statsLevel >= 2) { waveAdd(P.stats + ST_ACTIVE, active ? 1u : 0u); waveAdd(P.stats + ST_NEIGHBOURS, neighbours); }
+}
+
 // TransferToOriginal (RS:575-582).  A pure copy, so the wave moves its tile's records cooperatively: four adjacent
 // lanes copy the four quarters of one record, and every instruction covers two image rows of the tile as two runs of
 // 512 contiguous bytes (one lane per record would touch 32 cache lines per instruction).

@@ -149,3 +149,32 @@ def test_banded_dispatches_of_one_frame_do_not_flip(gpu_ctx, scene_small):
         gpu_ctx.set_row_band(0, 0)
         full.close()
         banded.close()
+
+
+@pytest.mark.parametrize("name,value", [("spatial_lds_max_offset", 3), ("spatial_lds_max_offset", 1), ("primary_background_groups", 64),
+                                        ("overlap_behind_candidates", 0)])
+def test_speed_only_choices_leave_every_bit_alone(gpu_ctx, scene_small, name, value):
+    """rt_set_tuning: the alternatives that were measured and not adopted still render the same frames - the LDS-staged
+    SpatialReusePass (also with a window of +-1, and with blocks at x < MaxOffset whose neighbours wrap into the row
+    above), primary rays as a background launch, primary rays started as early as their inputs allow."""
+    cfg = h.small_config(488, 264)   # 31 x 17 blocks, ragged on both edges
+    cfg.SpatialReuseBlur = 1 if (name, value) == ("spatial_lds_max_offset", 1) else 3
+    try:
+        plain = rt.Driver(gpu_ctx, cfg, scene_small)
+        for _ in range(4):
+            plain.render_frame()
+        want = snapshot(plain)
+        plain.close()
+        gpu_ctx.set_tuning(name, value)
+        tuned = rt.Driver(gpu_ctx, cfg, scene_small)
+        for _ in range(4):
+            tuned.render_frame()
+        got = snapshot(tuned)
+        tuned.close()
+        for k in want:
+            assert np.array_equal(h.bits(want[k]), h.bits(got[k])), k
+        with pytest.raises(rt.NativeError):
+            gpu_ctx.set_tuning("no_such_choice", 1)
+    finally:
+        for n, v in (("spatial_lds_max_offset", 0), ("primary_background_groups", 0), ("overlap_behind_candidates", 1)):
+            gpu_ctx.set_tuning(n, v)
