@@ -32,6 +32,9 @@ constexpr int WAVES_PER_BLOCK = 4;
 #define RT_MIN_WAVES 1
 #endif
 #define TRAVERSE traverse3
+#ifndef RT_RIS_FAST_DIV
+#define RT_RIS_FAST_DIV 1   // 0: the RIS project's box test always takes the division sequence (for A/B measurements)
+#endif
 
 struct v2 { float x, y; };
 struct v3 { float x, y, z; };
@@ -308,6 +311,42 @@ DEV float RayBVIntersectDiv(v3 pos, v3 dir, v3 bmin, v3 bmax) {
     return didHit ? (tNear > 0 ? tNear : 0.0f) : INF();
 }
 
+// The same twelve quotients without the division sequence (ten instructions each), where that is exact.  With
+// r = RN(1 / d) (rcpExact), q0 = RN(a * r) lies within one unit in the last place of a / d, the residual e = a - d * q0 is
+// exact in one fused multiply-add, and RN(q0 + e * r) is then the correctly rounded quotient (Markstein's correction
+// step) - as long as nothing on the way leaves the normal range.  That is secured by ranges, not assumed: the ray's
+// direction components within 2^-40 .. 2^40 (checked once per ray and object: divisorsInRange), every numerator of the
+// step within 2^-60 .. 2^59 in magnitude (one min / max chain over the twelve); then quotients stay within
+// 2^-100 .. 2^99 and residuals above 2^-124.  A step that fails either test - a ray parallel to an axis, an origin on a
+// box plane, infinities - takes RayBVIntersectDiv as written.  tools/micro/div_check.hip compares the three-instruction
+// quotient with the division over 2^32 random pairs and the edges of those ranges on the GPU.
+DEV bool divisorsInRange(v3 d) {
+    const uint32_t ex = (__float_as_uint(d.x) >> 23) & 0xffu, ey = (__float_as_uint(d.y) >> 23) & 0xffu, ez = (__float_as_uint(d.z) >> 23) & 0xffu;
+    return ex - 87u <= 80u && ey - 87u <= 80u && ez - 87u <= 80u;
+}
+DEV float quotientInRange(float a, float d, float r) {
+    const float q0 = a * r;
+    return __builtin_fmaf(__builtin_fmaf(-d, q0, a), r, q0);
+}
+DEV bool RayBVIntersectDivPairFast(v3 pos, v3 dir, v3 rcp, float4 q0, float4 q1, float4 q2, float& dstA, float& dstB) {
+    const float aMinX = q0.x - pos.x, aMinY = q0.y - pos.y, aMinZ = q2.x - pos.z, aMaxX = q0.z - pos.x, aMaxY = q0.w - pos.y, aMaxZ = q2.z - pos.z;
+    const float bMinX = q1.x - pos.x, bMinY = q1.y - pos.y, bMinZ = q2.y - pos.z, bMaxX = q1.z - pos.x, bMaxY = q1.w - pos.y, bMaxZ = q2.w - pos.z;
+    auto mag = [](float x) { return __builtin_fabsf(x); };
+    const float lo = fminf_(fminf_(fminf_(fminf_(mag(aMinX), mag(aMinY)), fminf_(mag(aMinZ), mag(aMaxX))), fminf_(fminf_(mag(aMaxY), mag(aMaxZ)), fminf_(mag(bMinX), mag(bMinY)))),
+                            fminf_(fminf_(mag(bMinZ), mag(bMaxX)), fminf_(mag(bMaxY), mag(bMaxZ))));
+    const float hi = fmaxf_(fmaxf_(fmaxf_(fmaxf_(mag(aMinX), mag(aMinY)), fmaxf_(mag(aMinZ), mag(aMaxX))), fmaxf_(fmaxf_(mag(aMaxY), mag(aMaxZ)), fmaxf_(mag(bMinX), mag(bMinY)))),
+                            fmaxf_(fmaxf_(mag(bMinZ), mag(bMaxX)), fmaxf_(mag(bMaxY), mag(bMaxZ))));
+    // (a NaN numerator is dropped by min / max and would slip through; it can only come from an infinite or NaN box or
+    // origin, and then another numerator of the same box is infinite or NaN as well... not relied upon: test the sum)
+    const float sum = ((aMinX + aMinY) + (aMinZ + aMaxX)) + ((aMaxY + aMaxZ) + (bMinX + bMinY)) + ((bMinZ + bMaxX) + (bMaxY + bMaxZ));
+    if (!(lo >= 0x1p-60f && hi <= 0x1p59f) || sum != sum) return false;
+    dstA = boxEntry(quotientInRange(aMinX, dir.x, rcp.x), quotientInRange(aMinY, dir.y, rcp.y), quotientInRange(aMinZ, dir.z, rcp.z),
+                    quotientInRange(aMaxX, dir.x, rcp.x), quotientInRange(aMaxY, dir.y, rcp.y), quotientInRange(aMaxZ, dir.z, rcp.z));
+    dstB = boxEntry(quotientInRange(bMinX, dir.x, rcp.x), quotientInRange(bMinY, dir.y, rcp.y), quotientInRange(bMinZ, dir.z, rcp.z),
+                    quotientInRange(bMaxX, dir.x, rcp.x), quotientInRange(bMaxY, dir.y, rcp.y), quotientInRange(bMaxZ, dir.z, rcp.z));
+    return true;
+}
+
 // GetRayCollision (RS:284-291) = TraverseSceneBVH (RS:219-282) + TraverseTrisBVH (RS:163-217), as one loop over one
 // stack.  `stk` points at this lane's column of the LDS stack (entries 64 dwords apart).  Visit order, the near-first
 // rule and the strict `<` culls are the reference's; only what is fetched per step, and when, differs.  Shading data
@@ -342,10 +381,12 @@ struct TravState {
     float localU, localV;
     uint32_t e;              // entry to visit next, or ENTRY_NONE
     uint32_t top;            // newest of the `sp` stacked entries (see travPush)
+    int divOk, wDivOk;       // RIS only: the direction of the level being traversed / of the world ray passes divisorsInRange
 };
 
-template <bool INSTR>
+template <bool INSTR, bool RIS = false>
 DEV void travBegin(const KParams& P, TravState& s, Trav& t, v3 wpos, v3 wdir, v3 winv, uint32_t* stk) {
+    if (RIS) { winv = rcp3(wdir); s.wDivOk = divisorsInRange(wdir) ? 1 : 0; s.divOk = s.wDivOk; }   // (the RIS callers pass no reciprocal)
     s.wpos = wpos; s.wdir = wdir; s.winv = winv;
     s.rpos = wpos; s.rdir = wdir; s.rinv = winv;
     s.best = INF(); s.worldBest = INF();
@@ -390,6 +431,7 @@ DEV void travService(const KParams& P, TravState& s, Trav& t, const uint32_t* st
         if (s.best < s.worldBest) { s.worldBest = s.best; t.tri = s.localTri; t.obj = s.curObj; t.u = s.localU; t.v = s.localV; }
         s.best = s.worldBest;
         s.rpos = s.wpos; s.rdir = s.wdir; s.rinv = s.winv;
+        if (RIS) s.divOk = s.wDivOk;
         s.inObj = 0;
         s.floor = (uint32_t*)stk;
     }
@@ -397,7 +439,8 @@ DEV void travService(const KParams& P, TravState& s, Trav& t, const uint32_t* st
         const float* m = P.objs[s.objCur].worldToLocalMatrix.m;
         s.rpos = mul44(m, s.wpos, 1.0f);
         s.rdir = mul44(m, s.wdir, 0.0f);
-        if (!RIS) s.rinv = rcp3(s.rdir);
+        s.rinv = rcp3(s.rdir);
+        if (RIS) s.divOk = divisorsInRange(s.rdir) ? 1 : 0;
         s.best = INF();
         s.localTri = -1;
         s.curObj = s.objCur;
@@ -424,8 +467,10 @@ DEV void travInternal(const KParams& P, TravState& s, Trav& t, uint32_t* stk) {
     const float2 q3 = *(const float2*)(rec + 3);  // the two child entries
     float dstA, dstB;
     if (RIS) {
-        dstA = RayBVIntersectDiv(s.rpos, s.rdir, V3(q0.x, q0.y, q2.x), V3(q0.z, q0.w, q2.z));
-        dstB = RayBVIntersectDiv(s.rpos, s.rdir, V3(q1.x, q1.y, q2.y), V3(q1.z, q1.w, q2.w));
+        if (!RT_RIS_FAST_DIV || !s.divOk || !RayBVIntersectDivPairFast(s.rpos, s.rdir, s.rinv, q0, q1, q2, dstA, dstB)) {
+            dstA = RayBVIntersectDiv(s.rpos, s.rdir, V3(q0.x, q0.y, q2.x), V3(q0.z, q0.w, q2.z));
+            dstB = RayBVIntersectDiv(s.rpos, s.rdir, V3(q1.x, q1.y, q2.y), V3(q1.z, q1.w, q2.w));
+        }
     } else {
         RayBVIntersectPair(s.rpos, s.rinv, q0, q1, q2, dstA, dstB);
     }
@@ -520,7 +565,7 @@ DEV void travTrip(const KParams& P, TravState& s, Trav& t, uint32_t* stk) {
 template <bool INSTR, bool RIS = false>
 DEV void traverse3(const KParams& P, const v3 wpos, const v3 wdir, const v3 winv, uint32_t* stk, Trav& t) {
     TravState s;
-    travBegin<INSTR>(P, s, t, wpos, wdir, winv, stk);
+    travBegin<INSTR, RIS>(P, s, t, wpos, wdir, winv, stk);
     while (__builtin_amdgcn_ballot_w64(s.e != ENTRY_DEAD) != 0) travTrip<INSTR, RIS>(P, s, t, stk);
 }
 
