@@ -84,7 +84,7 @@ int rt_flush(rt_ctx ctx);
  * current one at every such dispatch, and launches them on a stream of its own beside the kernels the dispatch stream
  * still holds; the dispatch stream waits for them before the candidate kernel.  Nothing a host can observe changes:
  * every readback, map and sync is ordered behind that wait, and buffers and textures read back what the dispatches, in
- * call order, left in them.  mode 0: off (RT_OVERLAP=0 for a process); 1 (default): for InitialTrace dispatches that
+ * call order, left in them.  mode 0: off (RT_OVERLAP=0 in the environment: off for the process, whatever is set here); 1 (default): for InitialTrace dispatches that
  * cover the whole image; 2: also for dispatches on a row band (rt_set_row_band) - the rows of HitInfos, DepthBuffer
  * and RayHitPointsA/B outside the band are then undefined after the dispatch, which is fine for a host that renders
  * the same band every frame (the multi-GPU frame loop) and wrong for one that renders several bands of one frame one

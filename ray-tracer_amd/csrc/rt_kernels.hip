@@ -336,10 +336,9 @@ DEV bool RayBVIntersectDivPairFast(v3 pos, v3 dir, v3 rcp, float4 q0, float4 q1,
                             fminf_(fminf_(mag(bMinZ), mag(bMaxX)), fminf_(mag(bMaxY), mag(bMaxZ))));
     const float hi = fmaxf_(fmaxf_(fmaxf_(fmaxf_(mag(aMinX), mag(aMinY)), fmaxf_(mag(aMinZ), mag(aMaxX))), fmaxf_(fmaxf_(mag(aMaxY), mag(aMaxZ)), fmaxf_(mag(bMinX), mag(bMinY)))),
                             fmaxf_(fmaxf_(mag(bMinZ), mag(bMaxX)), fmaxf_(mag(bMaxY), mag(bMaxZ))));
-    // (a NaN numerator is dropped by min / max and would slip through; it can only come from an infinite or NaN box or
-    // origin, and then another numerator of the same box is infinite or NaN as well... not relied upon: test the sum)
-    const float sum = ((aMinX + aMinY) + (aMinZ + aMaxX)) + ((aMaxY + aMaxZ) + (bMinX + bMinY)) + ((bMinZ + bMaxX) + (bMaxY + bMaxZ));
-    if (!(lo >= 0x1p-60f && hi <= 0x1p59f) || sum != sum) return false;
+    // (a NaN numerator is dropped by min / max and slips through: its quotient is a NaN either way, and boxEntry's own
+    // min / max drop it again)
+    if (!(lo >= 0x1p-60f && hi <= 0x1p59f)) return false;
     dstA = boxEntry(quotientInRange(aMinX, dir.x, rcp.x), quotientInRange(aMinY, dir.y, rcp.y), quotientInRange(aMinZ, dir.z, rcp.z),
                     quotientInRange(aMaxX, dir.x, rcp.x), quotientInRange(aMaxY, dir.y, rcp.y), quotientInRange(aMaxZ, dir.z, rcp.z));
     dstB = boxEntry(quotientInRange(bMinX, dir.x, rcp.x), quotientInRange(bMinY, dir.y, rcp.y), quotientInRange(bMinZ, dir.z, rcp.z),

@@ -1356,7 +1356,8 @@ int rt_set_overlap(rt_ctx ctx, int mode) {
     int rc = useDevice(ctx);
     if (rc) return rc;
     SK(ctx);
-    ctx->overlap = mode;
+    static const bool processOff = [] { const char* e = getenv("RT_OVERLAP"); return e && atoi(e) == 0; }();
+    ctx->overlap = processOff ? 0 : mode;   // RT_OVERLAP=0 switches it off for the whole process, whatever is asked for later
     ctx->afterCandidatesValid = false;
     ctx->mainDirty = true;   // the next overlapped primary rays follow all of stream0
     return finish(ctx);

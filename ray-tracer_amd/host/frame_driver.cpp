@@ -595,6 +595,9 @@ rth_mg mgCreate(rth_mg g, int rank, int world, const int* bounds, const unsigned
         int rc = rccl().CommInitRank(&g->comm, world, id, rank);  // on the device current in this thread (rt_create made it so)
         if (rc != 0) return fail(std::string("ncclCommInitRank: ") + rccl().GetErrorString(rc));
     }
+    // this rank renders the same band every frame and never reads per-pixel data outside band and halo: its primary
+    // rays may run beside the previous frame's kernels although they cover only part of the image
+    rt_set_overlap(g->ctx, 2);
     return g;
 }
 }  // namespace
@@ -622,6 +625,7 @@ void rth_mg_destroy(rth_mg g) {
     if (g->comm) { rt_sync(g->ctx); rccl().CommDestroy(g->comm); }
     rt_sync(g->ctx);
     rt_set_row_band(g->ctx, 0, 0);
+    rt_set_overlap(g->ctx, 1);
     delete g;
 }
 const char* rth_mg_last_error(rth_mg g) { return g ? g->err.c_str() : "null"; }
@@ -935,23 +939,35 @@ int rth_mg_balance(rth_mg g) {
     if (!g || !g->m) return -1;
     if (g->world == 1) return 0;
     if (!g->comm) { g->err = "this rank was created without a communicator"; return -1; }
-    std::vector<double> cost((size_t)g->H);
-    if (rth_mg_row_costs(g, cost.data()) != 0) return -1;
+    // A collective: a rank that fails on its own must still join the all-reduce, or the others wait for it for ever.
+    // So the buffer the all-reduce works on is made first (a failure there is the one case this rank cannot report
+    // through the collective), and the measurement's outcome travels in one extra element: every rank sees the number
+    // of ranks that failed and all of them give up together.
+    const size_t n = (size_t)g->H + 1;
+    std::vector<double> cost(n, 0.0);
     rt_buffer buf = nullptr;
+    rt_segment seg[4];
+    int cnt = 0;
+    void* stream = rt_transfer_stream(g->ctx);
+    if (!stream || rt_buffer_create(g->ctx, (int64_t)n, 8, &buf) < 0 || rt_buffer_map_rows(buf, 1, 0, (int)n, seg, &cnt) < 0) {
+        g->err = std::string("rth_mg_balance could not set up its exchange buffer: ") + rt_last_error(g->ctx);
+        rt_buffer_release(buf);
+        return -1;
+    }
+    std::string localFailure;
+    if (rth_mg_row_costs(g, cost.data()) != 0) { localFailure = g->err; cost.assign(n, 0.0); cost[n - 1] = 1.0; }
     int rc = -1;
     try {
-        mgCheck(g, rt_buffer_create(g->ctx, g->H, 8, &buf), "rt_buffer_create");
-        mgCheck(g, rt_buffer_set_data(buf, cost.data(), cost.size() * 8), "rt_buffer_set_data");
-        rt_segment seg[4];
-        int cnt = 0;
-        mgCheck(g, rt_buffer_map_rows(buf, 1, 0, g->H, seg, &cnt), "rt_buffer_map_rows");
-        void* stream = rt_transfer_stream(g->ctx);
-        if (!stream) throw DriverError{rt_last_error(g->ctx)};
+        if (rt_buffer_set_data(buf, cost.data(), n * 8) < 0) {   // (the upload failed: join with whatever the buffer holds, flagged below)
+            if (localFailure.empty()) localFailure = std::string("rt_buffer_set_data: ") + rt_last_error(g->ctx);
+        }
         mgOrder(g, 0);
-        int nrc = rccl().AllReduce(seg[0].ptr, seg[0].ptr, (size_t)g->H, NCCL_DOUBLE, NCCL_SUM, g->comm, stream);
+        int nrc = rccl().AllReduce(seg[0].ptr, seg[0].ptr, n, NCCL_DOUBLE, NCCL_SUM, g->comm, stream);
         if (nrc != 0) throw DriverError{std::string("ncclAllReduce: ") + rccl().GetErrorString(nrc)};
         mgOrder(g, 1);
-        mgCheck(g, rt_buffer_get_data(buf, cost.data(), cost.size() * 8), "rt_buffer_get_data");
+        mgCheck(g, rt_buffer_get_data(buf, cost.data(), n * 8), "rt_buffer_get_data");
+        if (!localFailure.empty()) throw DriverError{localFailure};
+        if (cost[n - 1] != 0.0) throw DriverError{"another rank could not measure its rows: no rank changes its cuts"};
         std::vector<int> b((size_t)g->world + 1);
         const int total = rth_mg_halo_plan(g->iterations, g->blur, nullptr, nullptr);
         if (rth_mg_balanced_bounds(g->H, g->world, cost.data(), total, b.data()) != 0) throw DriverError{"no balanced cuts exist for this image"};
