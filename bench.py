@@ -83,7 +83,12 @@ def source_hash():
     return h.hexdigest()[:16]
 
 
-PMC_FILE = os.path.join(ROOT, "profiles", "r02_pmc.json")
+def pmc_file(W, H, small_scene, scene, project, extra=None):
+    """The committed PMC passes of one workload: profiles/r03_pmc_<project>_<scene>_<W>x<H>[...].json."""
+    tag = f"{project}_{scene}{'_small' if small_scene else ''}_{W}x{H}"
+    for k, v in sorted((extra or {}).items()):
+        tag += f"_{k}{v}"
+    return os.path.join(ROOT, "profiles", f"r03_pmc_{tag}.json")
 
 
 def pmc_profile(W, H, world, small_scene, scene, project, extra=None):
@@ -91,9 +96,10 @@ def pmc_profile(W, H, world, small_scene, scene, project, extra=None):
     (tools/collect_profiles.sh -> tools/make_pmc_profile.py), or (None, reason) when they do not describe this run:
     another workload, or a library built from other sources than the ones the counters were collected on.
     Hardware counters cannot be read from inside the process being timed."""
-    if not os.path.exists(PMC_FILE):
-        return None, "no committed PMC passes (profiles/r02_pmc.json)"
-    prof = json.load(open(PMC_FILE))
+    path = pmc_file(W, H, small_scene, scene, project, extra)
+    if not os.path.exists(path):
+        return None, f"no committed PMC passes for this workload ({os.path.relpath(path, ROOT)})"
+    prof = json.load(open(path))
     want = {"width": W, "height": H, "world": world, "small_scene": small_scene, "scene": scene, "project": project}
     if extra:
         want.update(extra)
@@ -223,13 +229,15 @@ def main():
 
     ctx = runner.ctx
     ctx.enable_stats(1)
-    # Warm-up, with every launch bracketed by events: tells which kernel dominates the frame.
+    for _ in range(args.warmup):   # untimed: tables ranked, temporal history built, clocks up
+        runner.render_frame()
+    runner.sync()
+    # Which kernel dominates the frame: the per-kernel table of 8 further untimed frames in steady state, every launch
+    # bracketed by events - the kernel with the largest time per frame (average launch x launches per frame).  (Not taken
+    # from the warm-up frames: with few of them the first, untypical frames decide.)
     ctx.profile_reset()
     ctx.profile_enable(True)
-    for i in range(args.warmup):
-        if i == args.warmup // 2 and i > 0:   # the first frames run before the regions are ranked and without history
-            runner.sync()
-            ctx.profile_reset()
+    for _ in range(8):
         runner.render_frame()
     runner.sync()
     wprof = ctx.profile()
@@ -308,7 +316,8 @@ def main():
                 entry["hbm_MB_per_launch"] = k["hbm_bytes_per_launch"] / 1e6
                 entry["hbm_GBs"] = k["hbm_bytes_per_launch"] / 1e9 / (entry["avg_ms"] / 1e3)
                 entry["hbm_frac"] = entry["hbm_GBs"] / HBM_PEAK_GBS
-                for key in ("valu_busy_frac", "wave_wait_frac", "ta_busy_frac", "td_busy_frac", "l1_accesses_per_cu_clk", "l1_hit_frac"):
+                for key in ("valu_busy_frac", "wave_wait_frac", "ta_busy_frac", "td_busy_frac", "l1_accesses_per_cu_clk", "l1_hit_frac", "l2_hit_frac",
+                            "hbm_fetch_MB_per_launch", "hbm_write_MB_per_launch"):
                     if key in k:
                         entry[key] = round(k[key], 3)
         # The roofline of the dominant kernel is drawn against the HBM roof with the bytes that really crossed it
@@ -329,18 +338,21 @@ def main():
             if d.get("algorithmic_MB_per_launch"):
                 roofline["algorithmic"] = {"MB_per_launch": d["algorithmic_MB_per_launch"], "GBs": d["achieved_GBs"],
                                            "times_the_hbm_traffic": d["algorithmic_MB_per_launch"] * 1e6 / traffic if traffic else None,
-                                           "served_by": "L1/L2: the scene (15 MB with the wide nodes and baked triangles) stays cache resident"}
+                                           "served_by": "L1 / L2 / Infinity Cache: what the traversal re-reads of the scene never reaches the DRAM"}
             if "valu_busy_frac" in d:   # no unit is saturated: the kernel is bound by its chains of dependent steps
                 roofline["limiter"] = {"kind": "latency of dependent traversal steps", "valu_busy_frac": d["valu_busy_frac"],
                                        "wave_wait_frac": d["wave_wait_frac"], "ta_busy_frac": d["ta_busy_frac"],
                                        "td_busy_frac": d["td_busy_frac"], "l1_accesses_per_cu_clk": d["l1_accesses_per_cu_clk"],
-                                       "l1_hit_frac": d["l1_hit_frac"]}
+                                       "l1_hit_frac": d["l1_hit_frac"], "l2_hit_frac": d.get("l2_hit_frac")}
         # this rank's rays over the time of the kernels that cast them (InitialTrace + TraceRays) only
         trav_ms = sum(v["avg_ms"] * v["launches_per_frame"] for k, v in kernels.items()
                       if k in ("primary", "candidates", "trace_rays", "ris_primary", "ris_trace_rays"))
         trav_rate = rays_local / args.steps / 1e6 / (trav_ms / 1e3) if trav_ms > 0 else None
         out = {
-            "metric": "Mrays/s (primary+shadow) " + ("RIS DL" if ris else "ReSTIR DL") + ", 80kScene 1080p",
+            "metric": "Mrays/s (primary+shadow) " + ("RIS DL" if ris else "ReSTIR DL") + ", " +
+                      {"80k": "80kScene", "instanced": "instanced 10M-triangle 80kScene", "unique": "10M-triangle 80kScene (distinct meshes)"}[args.scene] +
+                      (" (8.7k-triangle dragon)" if args.small_scene else "") +
+                      (" 1080p" if (W, H) == (1920, 1080) else " 4K" if (W, H) == (3840, 2160) else f" {W}x{H}"),
             "value": rays_total / 1e6 / dt_max, "unit": "Mrays/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": dt_max / args.steps * 1e3, "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",

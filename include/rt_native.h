@@ -89,7 +89,16 @@ int rt_flush(rt_ctx ctx);
  * and RayHitPointsA/B outside the band are then undefined after the dispatch, which is fine for a host that renders
  * the same band every frame (the multi-GPU frame loop) and wrong for one that renders several bands of one frame one
  * after the other.  Device pointers from rt_buffer_map_rows / rt_texture_map_rows of those four objects are valid until
- * the next such dispatch.  No counterpart in the reference. */
+ * the next such dispatch.
+ * Two frames in flight: with a second copy of Candidates and CandidatesB as well (made at the first overlapped
+ * InitialTrace; 64 + 4 bytes per pixel each, the 4 being a per-copy tag that tells a readback which copy holds a pixel's
+ * newest record), consecutive frames share only TemporalFrameBuffer, Result / AccumulatedResult and the block tables,
+ * so the library alternates the frames between two dispatch streams and orders only the launches that touch those.
+ * What a host observes is unchanged; what changes is that "the dispatch stream" of rt_stream_order / rt_mark is the
+ * stream of the frame being dispatched.  rt_stream() ends it for the context (the host's own work on that stream must
+ * see every dispatch), rt_set_tuning "frames_in_flight" = 1 / RT_FRAMES_IN_FLIGHT=1 switch it off.  In mode 2 the
+ * reservoir records of a pixel whose primary ray missed are whatever the current copy holds, and rows written through
+ * rt_buffer_map_rows pointers are reported with rt_buffer_rows_written.  No counterpart in the reference. */
 int rt_set_overlap(rt_ctx ctx, int mode);
 /* Implementation choices that change speed only, never results; each also has an environment variable that sets the
  * default of new contexts.  Kept so that the alternatives that were measured and not adopted stay testable:
@@ -99,6 +108,9 @@ int rt_set_overlap(rt_ctx ctx, int mode);
  *                                 that walk the block table (0: one workgroup per block)
  *   "overlap_behind_candidates"  (RT_OVERLAP_START, default 1) overlapped primary rays of the ReSTIR project start only
  *                                 after the previous frame's candidate kernel (0: as early as their inputs allow)
+ *   "frames_in_flight"           (RT_FRAMES_IN_FLIGHT, default 2) 2: consecutive frames alternate between two dispatch
+ *                                 streams (see rt_set_overlap); 1: one dispatch stream.  Setting 2 after rt_stream()
+ *                                 tells the library that the host no longer uses that stream
  * Unknown names fail with RT_ERR_INVALID_ARG.  No counterpart in the reference. */
 int rt_set_tuning(rt_ctx ctx, const char* name, int value);
 /* enabled = 0: every dispatch is launched by the call that makes it (nothing is held or merged); 1 (the default
@@ -230,6 +242,10 @@ typedef struct {
     size_t bytes;
 } rt_segment;
 int rt_buffer_map_rows(rt_buffer buf, int width, int row0, int row1, rt_segment out[4], int* count);
+/* After the host (or a transfer) has written rows [row0, row1) through pointers from rt_buffer_map_rows: makes those
+ * rows of the current copy the ones a readback returns.  Needed only in overlap mode 2 for a reservoir buffer the
+ * library keeps two copies of (in the other modes rt_buffer_map_rows has already seen to it); harmless otherwise. */
+int rt_buffer_rows_written(rt_buffer buf, int width, int row0, int row1);
 int rt_texture_map_rows(rt_texture tex, int row0, int row1, rt_segment* out);
 
 /* ---- second stream for transfers (no counterpart in the reference) ---------------------------------------- */

@@ -70,6 +70,7 @@ internal static class RtNative
 
     // multi-GPU row access and the transfer stream
     [DllImport(Lib)] public static extern int rt_buffer_map_rows(IntPtr buffer, int width, int row0, int row1, [Out] RtSegment[] segments4, out int count);
+    [DllImport(Lib)] public static extern int rt_buffer_rows_written(IntPtr buffer, int width, int row0, int row1);
     [DllImport(Lib)] public static extern int rt_texture_map_rows(IntPtr texture, int row0, int row1, out RtSegment segment);
     [DllImport(Lib)] public static extern IntPtr rt_transfer_stream(IntPtr ctx);
     [DllImport(Lib)] public static extern int rt_stream_order(IntPtr ctx, int first);

@@ -82,6 +82,7 @@ def native_lib():
             "rt_texture_set_data": (ci, [vp, vp, C.c_size_t]), "rt_texture_get_data": (ci, [vp, vp, C.c_size_t]),
             "rt_texture_release": (None, [vp]),
             "rt_buffer_map_rows": (ci, [vp, ci, ci, ci, vp, C.POINTER(ci)]), "rt_texture_map_rows": (ci, [vp, ci, ci, vp]),
+            "rt_buffer_rows_written": (ci, [vp, ci, ci, ci]),
             "rt_enable_stats": (ci, [vp, ci]), "rt_get_stats": (ci, [vp, ci, vp]),
             "rt_profile_enable": (ci, [vp, ci]), "rt_profile_select": (ci, [vp, cs]), "rt_profile_reset": (ci, [vp]), "rt_profile_get": (ci, [vp, cs, vp]),
         }

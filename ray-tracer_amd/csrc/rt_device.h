@@ -50,9 +50,16 @@ struct Planes {
 // Candidates and CandidatesB are also GATHERED, from random neighbouring pixels (SpatialReusePass reads nine per pixel
 // and pass): there a reservoir is one aligned 64-byte record, so a gathered one costs one cache line instead of four.
 //   q0 = dir.xyz, chosenWeight   q1 = hitPoint.xyz, totWeights   q2 = normal.xyz, totCandidates   q3 = brdf, 0, 0, 0
+// When the library keeps two copies of such a buffer (one per frame in flight, rt_native.hip), every copy has a tag per
+// pixel: the number (rt_ctx_s::epoch, never 0) of the frame that last wrote the pixel's record INTO THAT COPY, stored
+// with every record.  Only the frames that work on a copy write its tags, so two frames in flight never write the same
+// tag.  A readback takes each pixel from the copy with the larger tag: pixels a frame does not write (no hit) still
+// read back what an earlier frame left, as with a single buffer.
 struct Recs {
     float4* q;  // 4 per pixel
     int64_t count;
+    uint32_t* tag;      // null: a single copy
+    uint32_t tagValue;  // the frame's number
 };
 
 struct Tex {

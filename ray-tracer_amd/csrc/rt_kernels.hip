@@ -662,6 +662,7 @@ DEV Reservoir emptyReservoir() {
     return r;
 }
 DEV void storeReservoir(const Recs& rc, int64_t i, const Reservoir& r) {
+    if (rc.tag) rc.tag[i] = rc.tagValue;
     float4* q = rc.q + i * 4;
     q[0] = make_float4(r.dir.x, r.dir.y, r.dir.z, r.chosenWeight);
     q[1] = make_float4(r.hitPoint.x, r.hitPoint.y, r.hitPoint.z, r.totWeights);
@@ -739,6 +740,7 @@ DEV void coopStoreReservoir(const KParams& P, const Recs& rc, int x0, int y0, un
         if ((mask >> owner) & 1ull) {
             const int64_t i = (int64_t)((uint32_t)P.ResX * (uint32_t)(y0 + row) + (uint32_t)(x0 + col));
             rc.q[i * 4 + piece] = stage[owner * COOP_ROW + piece];
+            if (rc.tag && piece == 0) rc.tag[i] = rc.tagValue;
         }
     }
     waveFenceLds();
@@ -1209,6 +1211,7 @@ __global__ __launch_bounds__(256) void k_transfer(const KParams P) {
             if ((mask >> (row * 8 + col)) & 1ull) {
                 const int64_t i = (int64_t)((uint32_t)P.ResX * (uint32_t)(y0 + row) + (uint32_t)(x0 + col));
                 P.cand.q[i * 4 + piece] = P.candB.q[i * 4 + piece];
+                if (P.cand.tag && piece == 0) P.cand.tag[i] = P.cand.tagValue;
             }
         }
     }
@@ -1487,16 +1490,32 @@ __global__ void k_aos_to_recs(const float* aos, Recs rc) {
     q[2] = make_float4(r[6], r[7], r[8], r[12]);
     q[3] = make_float4(r[9], 0.0f, 0.0f, 0.0f);
 }
-__global__ void k_recs_to_aos(Recs rc, float* aos, int64_t first, int64_t n) {
+// `other`, `otherTag`: the buffer's second copy and its tags, or null; a pixel whose newest record is there (the larger
+// tag) is taken from there.
+__global__ void k_recs_to_aos(Recs rc, const float4* other, const uint32_t* otherTag, float* aos, int64_t first, int64_t n) {
     int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= n) return;
     float* r = aos + j * 13;
-    const float4* q = rc.q + (first + j) * 4;
+    const bool fromOther = other && otherTag && rc.tag && otherTag[first + j] > rc.tag[first + j];
+    const float4* q = (fromOther ? other : rc.q) + (first + j) * 4;
     float4 a = q[0], b = q[1], c = q[2], d = q[3];
     r[0] = a.x; r[1] = a.y; r[2] = a.z; r[10] = a.w;
     r[3] = b.x; r[4] = b.y; r[5] = b.z; r[11] = b.w;
     r[6] = c.x; r[7] = c.y; r[8] = c.z; r[12] = c.w;
     r[9] = d.x;
+}
+// Makes the copy `rc` of a two-copy record buffer complete for records [first, first + n): a pixel whose newest record is
+// in the other copy gets that record, and its tag.  (Run with no frame in flight.)
+__global__ void k_recs_merge(Recs rc, const float4* other, const uint32_t* otherTag, int64_t first, int64_t n) {
+    int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n * 4) return;
+    const int64_t i = first + (j >> 2);
+    const int piece = (int)(j & 3);
+    const uint32_t t = otherTag[i], mine = rc.tag[i];
+    if (t <= mine) return;
+    rc.q[i * 4 + piece] = other[i * 4 + piece];
+    // (the four lanes of a record are neighbours in one wave: all have loaded the tag before this store is issued)
+    if (piece == 0) rc.tag[i] = t;
 }
 // Rebuilds the workgroup -> block table with the heaviest 64x64-pixel regions first (longest-processing-time-first:
 // the launches that follow end with light regions instead of with a few heavy waves on an otherwise idle chip).

@@ -61,20 +61,51 @@ struct rt_ctx_s {
     // TransferToOriginal, TraceRays) and the hit-point target of its parity (TemporalReuse reads both targets).  The
     // library keeps a second copy of each of those, writes the copy that is NOT current and makes it the current one
     // at the dispatch, and launches the primary rays on `stream1`, where they queue behind one another and run beside
-    // whatever stream0 holds; stream0 waits for them (`evPrimary`) before the candidate kernel.  The copy being written
-    // was last read by the frame before the previous one: `evReaders[k]`, recorded on stream0 at every such dispatch
-    // (alternately k = 0, 1), marks where those readers end, and stream1 waits for the older of the two.
-    // Everything a host can observe stays in call order: every readback, map and sync goes through stream0, which has
-    // the wait for the primary rays enqueued by the time the dispatch returns, and reads the current copies.
-    // `mainDirty`: something other than the frame's own kernels was put on stream0 since (a scene rebuild, a cleared new
+    // whatever the frame streams hold; the frame's stream waits for them (`evPrimary`) before the candidate kernel.
+    // Everything a host can observe stays in call order: every readback, map and sync goes through stream0 behind all
+    // other streams, and reads the current copies.
+    // `mainDirty`: something other than the frames' own kernels was put on stream0 since (a scene rebuild, a cleared new
     // buffer, primary rays that could not be overlapped, work of the host's own after rt_stream): the next primary
-    // rays then wait for all of stream0.
+    // rays then wait for all of it.
     // overlap: 0 off, 1 (default) InitialTrace dispatches that cover the whole image, 2 also those on a row band (the
-    // rows outside the band are then undefined in the flipped objects: a multi-GPU host never reads them).
+    // rows outside the band are then undefined in the objects with two copies: a multi-GPU host never reads them).
     hipStream_t stream1 = nullptr;
-    hipEvent_t evReaders[2] = {nullptr, nullptr}, evPrimary = nullptr;
-    bool readersValid[2] = {false, false};
-    int ring = 0;
+    hipEvent_t evPrimary = nullptr;
+    // Two frames in flight.  With a second copy of Candidates and CandidatesB as well, the kernels of frame f+1 touch
+    // nothing the kernels of frame f touch, except TemporalFrameBuffer (TemporalReuse of f+1 reads what that of f wrote),
+    // Result / AccumulatedResult (TraceRays and AccumulateFrames of f+1 after those of f) and the block tables.  So the
+    // frames alternate between two dispatch streams, frameStream[0] (= stream0) and frameStream[1]: frame f+1's candidate
+    // kernel and reuse passes run beside frame f's reuse passes and TraceRays, which is what fills the GPU when a launch
+    // covers a row band only (a 136-row band of a 3840x2160 frame: 0.48 -> 0.37 ms per frame).  Orders that are kept:
+    //  * a launch that touches one of the shared objects waits for the last launch on the OTHER frame stream that did
+    //    (evShared[object][stream]); launches on one stream are in order anyway;
+    //  * the copies frame f+1 writes were current during frame f-1: at every InitialTrace that changes copies, the tails
+    //    of both frame streams are recorded for the copies being left (evSetFree[set][stream]), and the streams that will
+    //    write the set that becomes current (stream1 and the new frame stream) wait for the records made when that set
+    //    was left;
+    //  * a frame kernel that is given a record buffer the frame's InitialTrace did not change copies of (rt_buffer_s::epoch)
+    //    first waits for the other frame stream (joinOther);
+    //  * anything else - an upload, a readback, a scene rebuild, rt_stream - goes to stream0 behind BOTH frame streams
+    //    (S(): collapse), and frame launches that follow on frameStream[1] wait for stream0 (dirty1);
+    //  * the table of the frame streams' kernels (BlockMap::dyn) is rewritten only with both frame streams joined.
+    // `cur`: the frame stream of the frame being dispatched; it changes at every InitialTrace whose primary rays are
+    // overlapped, when framesInFlight is 2 (rt_set_tuning "frames_in_flight", RT_FRAMES_IN_FLIGHT; 1 = one frame stream)
+    // and the host has not asked for the dispatch stream itself (rt_stream: streamShared, one frame stream from then on).
+    hipStream_t frameStream[2] = {nullptr, nullptr};
+    int cur = 0;
+    int framesInFlight = 2;
+    bool streamShared = false;
+    bool stream1Pending = false;   // frameStream[1] holds work stream0 has not been made to wait for
+    bool dirty1 = true;            // stream0 holds work frameStream[1] has not been made to wait for
+    hipEvent_t evJoin = nullptr, evTail0 = nullptr, evOther = nullptr, evTable = nullptr;
+    enum { SH_TEMPORAL = 0, SH_RESULT = 1, SH_COUNT = 2 };
+    hipEvent_t evShared[SH_COUNT][2] = {};
+    bool sharedValid[SH_COUNT][2] = {};
+    hipEvent_t evSetFree[2][2] = {};
+    bool setFreeValid[2][2] = {};
+    int curSet = 0;                // the set of copies that is current (changes with every overlapped InitialTrace)
+    uint64_t epoch = 2;            // number of the frame being dispatched, for the record tags (+1 whenever copies change)
+    std::vector<rt_buffer> tagged; // the record buffers that have two copies
     // By choice (the default) the primary rays also wait for `evAfterCandidates`, recorded on stream0 behind every
     // candidate-kernel launch: they then run beside the previous frame's SpatialReusePass and TraceRays launches only,
     // not beside its candidate kernel, which measured a little faster on one GPU (0.745 against 0.756 ms per 1080p frame,
@@ -168,7 +199,13 @@ struct rt_buffer_s {
     void* dev;
     int layout;
     uint64_t version;
-    void* alt = nullptr;  // HitInfos only: the copy the next frame's primary rays write (see rt_ctx_s::stream1)
+    void* alt = nullptr;  // HitInfos, Candidates, CandidatesB: the copy the next frame works on (see rt_ctx_s::stream1, frameStream)
+    // Candidates / CandidatesB only (frames write them for hit pixels alone): per copy and pixel, the number of the
+    // frame that last wrote the pixel's record into that copy (see Recs).  A readback takes each pixel from the copy
+    // with the larger tag.
+    uint32_t* tag = nullptr;     // of the copy `dev`
+    uint32_t* tagAlt = nullptr;  // of the copy `alt`
+    uint64_t epoch = 0;          // rt_ctx_s::epoch when the copies last changed places
 };
 
 struct rt_texture_s {
@@ -242,17 +279,57 @@ void launchHeld(rt_ctx ctx);
 // The dispatch stream, for everything except the merged launches themselves: what is held back goes first.
 // SK: for the frame's own kernels and for calls that put nothing on the stream the next frame's primary rays could
 // conflict with.  S: anything else (marks the stream dirty, see rt_ctx_s::mainDirty).
+// The stream of the frame being dispatched (no held launch first).  On frameStream[1], work that went onto stream0
+// meanwhile (dirty1) is waited for first.
+hipStream_t frameStreamNow(rt_ctx ctx) {
+    if (ctx->cur == 1) {
+        if (ctx->dirty1) {
+            if (hipEventRecord(ctx->evTail0, ctx->stream0) == hipSuccess && hipStreamWaitEvent(ctx->frameStream[1], ctx->evTail0, 0) == hipSuccess) ctx->dirty1 = false;
+        }
+        ctx->stream1Pending = true;
+    }
+    return ctx->frameStream[ctx->cur];
+}
+// stream0 behind everything the other frame stream holds.
+void collapse(rt_ctx ctx) {
+    if (!ctx->stream1Pending) return;
+    if (hipEventRecord(ctx->evJoin, ctx->frameStream[1]) == hipSuccess && hipStreamWaitEvent(ctx->stream0, ctx->evJoin, 0) == hipSuccess) ctx->stream1Pending = false;
+}
 hipStream_t SK(rt_ctx ctx) {
     if (ctx->held.kind) launchHeld(ctx);
-    return ctx->stream0;
+    return frameStreamNow(ctx);
 }
 hipStream_t S(rt_ctx ctx) {
+    if (ctx->held.kind) launchHeld(ctx);
+    collapse(ctx);
     ctx->mainDirty = true;
-    return SK(ctx);
+    ctx->dirty1 = true;
+    return ctx->stream0;
 }
-void markAfterCandidates(rt_ctx ctx) {
+// Back to the one dispatch stream, behind everything (the start of a frame that will not run beside the one before).
+void useMainStream(rt_ctx ctx) {
+    if (ctx->held.kind) launchHeld(ctx);
+    collapse(ctx);
+    ctx->cur = 0;
+}
+// Before / after a launch of the frame being dispatched that touches a single-copy object both frames in flight use.
+void waitShared(rt_ctx ctx, int object, hipStream_t stream) {
+    const int other = ctx->cur ^ 1;
+    if (ctx->sharedValid[object][other]) { hipError_t e = hipStreamWaitEvent(stream, ctx->evShared[object][other], 0); (void)e; }
+}
+void markShared(rt_ctx ctx, int object, hipStream_t stream) {
+    ctx->sharedValid[object][ctx->cur] = hipEventRecord(ctx->evShared[object][ctx->cur], stream) == hipSuccess;
+}
+// The stream of the frame being dispatched waits for all the other frame stream holds.
+void joinOther(rt_ctx ctx) {
+    const int other = ctx->cur ^ 1;
+    if (other == 1 && !ctx->stream1Pending) return;   // (nothing there that stream0 is not already behind)
+    hipStream_t mine = frameStreamNow(ctx);
+    if (hipEventRecord(ctx->evOther, ctx->frameStream[other]) == hipSuccess) { hipError_t e = hipStreamWaitEvent(mine, ctx->evOther, 0); (void)e; }
+}
+void markAfterCandidates(rt_ctx ctx, hipStream_t stream) {
     if (!ctx->overlap || !ctx->behindCandidates || !ctx->evAfterCandidates) return;
-    ctx->afterCandidatesValid = hipEventRecord(ctx->evAfterCandidates, ctx->stream0) == hipSuccess;
+    ctx->afterCandidatesValid = hipEventRecord(ctx->evAfterCandidates, stream) == hipSuccess;
 }
 
 Planes planesOf(rt_buffer b) {
@@ -270,6 +347,8 @@ Recs recsOf(rt_buffer b) {
     Recs r;
     r.q = (float4*)b->dev;
     r.count = b->count;
+    r.tag = b->tag;
+    r.tagValue = (uint32_t)b->ctx->epoch;
     return r;
 }
 // Device bytes of a buffer in a given layout: reservoir records are padded from 52 to 64 bytes.
@@ -280,10 +359,33 @@ void launchToAos(rt_buffer b, void* dst, int64_t first = 0, int64_t n = -1) {
     if (n < 0) n = b->count - first;
     if (n <= 0) return;
     const int blocks = (int)((n + 255) / 256);
-    if (b->layout == LAYOUT_RESERVOIR_RECS) hipLaunchKernelGGL(k_recs_to_aos, dim3(blocks), dim3(256), 0, S(b->ctx), recsOf(b), (float*)dst, first, n);
+    if (b->layout == LAYOUT_RESERVOIR_RECS) hipLaunchKernelGGL(k_recs_to_aos, dim3(blocks), dim3(256), 0, S(b->ctx), recsOf(b), b->tag ? (const float4*)b->alt : nullptr, b->tagAlt, (float*)dst, first, n);
     else hipLaunchKernelGGL(k_planes_to_aos, dim3(blocks), dim3(256), 0, S(b->ctx), planesOf(b), (float*)dst, b->layout == LAYOUT_RESERVOIR_PLANES ? 0 : 1, first, n);
 }
 
+// A record buffer goes back to a single copy (the caller deals with `alt`).
+void dropTags(rt_buffer b) {
+    hipError_t e = hipSuccess;
+    if (b->tag) e = hipFree(b->tag);
+    if (b->tagAlt) e = hipFree(b->tagAlt);
+    (void)e;
+    b->tag = b->tagAlt = nullptr;
+    auto& v = b->ctx->tagged;
+    v.erase(std::remove(v.begin(), v.end(), b), v.end());
+}
+// Completes the current copy of records [first, first + n) of a two-copy record buffer (all of them: n < 0), on stream0
+// behind everything: afterwards that copy alone is what a single buffer would hold.
+void mergeRecords(rt_buffer b, int64_t first = 0, int64_t n = -1) {
+    if (!b->tag || !b->alt) return;
+    if (n < 0) n = b->count - first;
+    if (n <= 0) return;
+    hipLaunchKernelGGL(k_recs_merge, dim3((unsigned)((n * 4 + 255) / 256)), dim3(256), 0, S(b->ctx), recsOf(b), (const float4*)b->alt, b->tagAlt, first, n);
+}
+// Before the host changes, or is given the address of, a per-pixel object the frames keep two copies of: which copy
+// holds a pixel's newest record follows from where the frames found hits, and that is what the host may now change.
+void settleRecords(rt_ctx ctx) {
+    for (rt_buffer b : ctx->tagged) mergeRecords(b);
+}
 // Switches a 52-byte-stride buffer between the ABI's array-of-structures layout and an internal one.
 int convertLayout(rt_buffer b, int target) {
     if (b->layout == target) return RT_OK;
@@ -298,6 +400,7 @@ int convertLayout(rt_buffer b, int target) {
     int blocks = (int)((b->count + 255) / 256);
     rt_buffer_s shadow = *b;
     shadow.dev = tmp;
+    shadow.tag = shadow.tagAlt = nullptr;
     if (target == LAYOUT_AOS) {
         launchToAos(b, tmp);
     } else if (target == LAYOUT_RESERVOIR_RECS) {
@@ -314,6 +417,16 @@ int convertLayout(rt_buffer b, int target) {
     }
     HIP_TRY(ctx, hipFree(b->dev));
     b->dev = tmp;
+    if (b->tag) {  // a tagged pair of record copies has just been merged into `tmp`: one copy again
+        dropTags(b);
+        hipError_t e3 = hipFree(b->alt);
+        (void)e3;
+        b->alt = nullptr;
+    } else if (b->alt && layoutBytes(b, target) != layoutBytes(b, b->layout)) {   // a second copy of another size is of no use
+        hipError_t e3 = hipFree(b->alt);
+        (void)e3;
+        b->alt = nullptr;
+    }
     b->layout = target;
     return RT_OK;
 }
@@ -523,11 +636,14 @@ int needPlanes(rt_shader sh, int kernel, const char* name, int layout, Planes& o
     out = planesOf(b);
     return RT_OK;
 }
-int needRecs(rt_shader sh, int kernel, const char* name, Recs& out) {
+// `duringFrame`: the kernel runs after the frame's InitialTrace; a buffer that dispatch did not give a copy of its own for
+// this frame may still be in use by the other frame in flight.
+int needRecs(rt_shader sh, int kernel, const char* name, Recs& out, bool duringFrame = true) {
     rt_buffer b = boundBuffer(sh, kernel, name);
     if (!b) return fail(sh->ctx, RT_ERR_UNBOUND, "kernel %d: buffer '%s' is not bound", kernel, name);
     int rc = convertLayout(b, LAYOUT_RESERVOIR_RECS);
     if (rc) return rc;
+    if (duringFrame && b->epoch != sh->ctx->epoch) joinOther(sh->ctx);
     out = recsOf(b);
     return RT_OK;
 }
@@ -725,7 +841,15 @@ void reorderBlocks(rt_ctx ctx, rt_ctx_s::BlockMap* m, bool primaryOnStream1) {
 void reorderBlocksMain(rt_ctx ctx, rt_ctx_s::BlockMap* m) {
     if (!m || !m->dyn || !m->pendingDyn) return;
     m->pendingDyn = false;
-    hipLaunchKernelGGL(k_order_blocks, dim3(1), dim3(1024), 0, SK(ctx), m->pendingMeasured ? m->steps : m->cost, m->bx, m->by, m->dyn, m->nDyn, m->pendingMeasured ? 1 : 0);
+    // kernels of the frame before may still be walking this table on the other frame stream: behind them, and the
+    // other stream's next launches behind the new table
+    hipStream_t st = SK(ctx);
+    joinOther(ctx);
+    hipLaunchKernelGGL(k_order_blocks, dim3(1), dim3(1024), 0, st, m->pendingMeasured ? m->steps : m->cost, m->bx, m->by, m->dyn, m->nDyn, m->pendingMeasured ? 1 : 0);
+    if (ctx->framesInFlight == 2 && !ctx->streamShared && hipEventRecord(ctx->evTable, st) == hipSuccess) {
+        hipError_t e = hipStreamWaitEvent(ctx->frameStream[ctx->cur ^ 1], ctx->evTable, 0);
+        (void)e;
+    }
     m->dynValid = true;
 }
 
@@ -770,37 +894,77 @@ int drainTiming(rt_ctx ctx) {
     return RT_OK;
 }
 
-// Prepares a dispatch whose primary rays run on stream1 beside what stream0 holds (see rt_ctx_s::stream1): makes the
-// second copy of every object in `flips` the current one, and orders stream1 behind the last readers of those copies.
-// Returns false (nothing changed) when that cannot be done; the caller then launches on stream0 as usual.
+// Prepares a dispatch whose primary rays run on stream1 beside what the frame streams hold (see rt_ctx_s::stream1,
+// frameStream): makes the second copy of every object in `flips`, and of the record buffers in `recs` (Candidates,
+// CandidatesB; entries may be null), the current one, orders stream1 and the frame's stream behind the last users of
+// those copies, and - `alternate` - moves on to the other frame stream.  Returns false (nothing changed) when that
+// cannot be done; the caller then launches on the one dispatch stream as usual.
 struct Flip { void** dev; void** alt; size_t bytes; };
-bool beginOverlappedPrimary(rt_ctx ctx, const Flip* flips, int n) {
-    if (!ctx->stream1 || !ctx->evReaders[0] || !ctx->evReaders[1] || !ctx->evPrimary) return false;
+bool beginOverlappedPrimary(rt_ctx ctx, const Flip* flips, int n, rt_buffer const* recs, int nRecs, bool alternate) {
+    if (!ctx->stream1 || !ctx->evPrimary || !ctx->frameStream[1]) return false;
+    const bool two = alternate && ctx->framesInFlight == 2 && !ctx->streamShared;
     for (int i = 0; i < n; i++) {
         if (*flips[i].alt) continue;
         if (hipMalloc(flips[i].alt, flips[i].bytes) != hipSuccess) { *flips[i].alt = nullptr; return false; }
         // (rows a banded launch never writes must not hold garbage a readback could return)
         if (hipMemsetAsync(*flips[i].alt, 0, flips[i].bytes, S(ctx)) != hipSuccess) return false;
     }
-    // everything enqueued so far reads (at most) the copies that are current now
-    const int k = ctx->ring;
-    if (hipEventRecord(ctx->evReaders[k], ctx->stream0) != hipSuccess) return false;
-    ctx->readersValid[k] = true;
+    for (int i = 0; i < nRecs; i++) {
+        rt_buffer b = recs[i];
+        if (!b || (b->alt && b->tag)) continue;
+        if (!two) continue;   // one frame stream: the records keep their single copy
+        if (b->layout != LAYOUT_RESERVOIR_RECS) return false;
+        const size_t bytes = layoutBytes(b, b->layout), tagBytes = (size_t)b->count * sizeof(uint32_t);
+        if (!b->alt && hipMalloc(&b->alt, bytes) != hipSuccess) { b->alt = nullptr; return false; }
+        if (hipMalloc((void**)&b->tag, tagBytes) != hipSuccess) { b->tag = nullptr; return false; }
+        if (hipMalloc((void**)&b->tagAlt, tagBytes) != hipSuccess) { hipError_t e = hipFree(b->tag); (void)e; b->tag = b->tagAlt = nullptr; return false; }
+        // what the buffer holds now is newer than the zeros of its new copy: tag 1 against tag 0
+        hipStream_t s0 = S(ctx);
+        if (hipMemsetAsync(b->alt, 0, bytes, s0) != hipSuccess || hipMemsetD32Async((hipDeviceptr_t)b->tag, 1, b->count, s0) != hipSuccess ||
+            hipMemsetAsync(b->tagAlt, 0, tagBytes, s0) != hipSuccess) {
+            dropTags(b);
+            return false;
+        }
+        ctx->tagged.push_back(b);
+    }
+    // everything enqueued so far uses (at most) the copies that are current now
+    const int s = ctx->curSet, o = s ^ 1;
+    if (hipEventRecord(ctx->evSetFree[s][0], ctx->stream0) != hipSuccess) return false;
+    ctx->setFreeValid[s][0] = true;
+    ctx->setFreeValid[s][1] = ctx->stream1Pending && hipEventRecord(ctx->evSetFree[s][1], ctx->frameStream[1]) == hipSuccess;
+    if (ctx->stream1Pending && !ctx->setFreeValid[s][1]) return false;
+    const int next = two ? ctx->cur ^ 1 : ctx->cur;
     if (ctx->mainDirty) {  // something else went onto stream0: behind all of it, once
-        if (hipStreamWaitEvent(ctx->stream1, ctx->evReaders[k], 0) != hipSuccess) return false;
+        collapse(ctx);
+        if (ctx->stream1Pending) return false;
+        if (hipEventRecord(ctx->evTail0, ctx->stream0) != hipSuccess || hipStreamWaitEvent(ctx->stream1, ctx->evTail0, 0) != hipSuccess) return false;
         ctx->mainDirty = false;
-    } else if (ctx->readersValid[k ^ 1]) {  // the copies written now were current until the dispatch before this one
-        if (hipStreamWaitEvent(ctx->stream1, ctx->evReaders[k ^ 1], 0) != hipSuccess) return false;
+        ctx->dirty1 = true;   // (and so does frameStream[1], at its next launch)
+    } else {               // the copies written from now on were current until the change of copies before this one
+        for (int k = 0; k < 2; k++) {
+            if (!ctx->setFreeValid[o][k]) continue;
+            if (hipStreamWaitEvent(ctx->stream1, ctx->evSetFree[o][k], 0) != hipSuccess) return false;
+            if (k != next && hipStreamWaitEvent(ctx->frameStream[next], ctx->evSetFree[o][k], 0) != hipSuccess) return false;
+        }
     }
     if (ctx->behindCandidates && ctx->afterCandidatesValid && hipStreamWaitEvent(ctx->stream1, ctx->evAfterCandidates, 0) != hipSuccess) return false;
-    ctx->ring = k ^ 1;
+    ctx->curSet = o;
+    ctx->cur = next;
+    ctx->epoch++;
     for (int i = 0; i < n; i++) std::swap(*flips[i].dev, *flips[i].alt);
+    for (int i = 0; i < nRecs; i++) {
+        rt_buffer b = recs[i];
+        if (!b || !b->tag) continue;
+        std::swap(b->dev, b->alt);
+        std::swap(b->tag, b->tagAlt);
+        b->epoch = ctx->epoch;
+    }
     return true;
 }
-// After the overlapped launch: stream0 goes on only when the primary rays are done.
+// After the overlapped launch: the frame's stream goes on only when the primary rays are done.
 int endOverlappedPrimary(rt_ctx ctx) {
     HIP_TRY(ctx, hipEventRecord(ctx->evPrimary, ctx->stream1));
-    HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream0, ctx->evPrimary, 0));
+    HIP_TRY(ctx, hipStreamWaitEvent(frameStreamNow(ctx), ctx->evPrimary, 0));
     return RT_OK;
 }
 bool mayOverlap(rt_ctx ctx, bool instr, const KParams& P) {
@@ -818,24 +982,39 @@ void launchHeld(rt_ctx ctx, bool acc) {
     // the caller may be an entry point that takes no device of its own (rt_stream, the map calls) in a process that
     // holds contexts on several GPUs
     { hipError_t e = hipSetDevice(ctx->device); (void)e; }
+    hipStream_t st = frameStreamNow(ctx);   // (the frame stream cannot have changed since the dispatch was held)
     if (h.kind == 1) {
-        LaunchScope ls(ctx, IK_TRANSFER, &h.P);
-        hipLaunchKernelGGL(k_transfer, dim3(h.blocks), dim3(256), 0, ctx->stream0, h.P);
+        LaunchScope ls(ctx, IK_TRANSFER, &h.P, st);
+        hipLaunchKernelGGL(k_transfer, dim3(h.blocks), dim3(256), 0, st, h.P);
     } else if (h.kind == 3) {
-        LaunchScope ls(ctx, IK_CANDIDATES, &h.P);
-        if (acc) hipLaunchKernelGGL((k_candidates<false, true>), dim3(h.blocks), dim3(256), h.ldsBytes, ctx->stream0, h.P);
-        else hipLaunchKernelGGL((k_candidates<false, false>), dim3(h.blocks), dim3(256), h.ldsBytes, ctx->stream0, h.P);
-        markAfterCandidates(ctx);
+        if (acc) waitShared(ctx, rt_ctx_s::SH_TEMPORAL, st);
+        {
+            LaunchScope ls(ctx, IK_CANDIDATES, &h.P, st);
+            if (acc) hipLaunchKernelGGL((k_candidates<false, true>), dim3(h.blocks), dim3(256), h.ldsBytes, st, h.P);
+            else hipLaunchKernelGGL((k_candidates<false, false>), dim3(h.blocks), dim3(256), h.ldsBytes, st, h.P);
+        }
+        if (acc) markShared(ctx, rt_ctx_s::SH_TEMPORAL, st);
+        markAfterCandidates(ctx, st);
     } else if (h.kind == 4) {
-        LaunchScope ls(ctx, IK_RIS_TRACE_RAYS, &h.P);
-        if (acc) hipLaunchKernelGGL((k_ris_trace_rays<false, true>), dim3(h.blocks), dim3(256), h.ldsBytes, ctx->stream0, h.P);
-        else hipLaunchKernelGGL((k_ris_trace_rays<false, false>), dim3(h.blocks), dim3(256), h.ldsBytes, ctx->stream0, h.P);
+        waitShared(ctx, rt_ctx_s::SH_RESULT, st);
+        {
+            LaunchScope ls(ctx, IK_RIS_TRACE_RAYS, &h.P, st);
+            if (acc) hipLaunchKernelGGL((k_ris_trace_rays<false, true>), dim3(h.blocks), dim3(256), h.ldsBytes, st, h.P);
+            else hipLaunchKernelGGL((k_ris_trace_rays<false, false>), dim3(h.blocks), dim3(256), h.ldsBytes, st, h.P);
+        }
+        markShared(ctx, rt_ctx_s::SH_RESULT, st);
     } else if (h.kind == 2) {
-        LaunchScope ls(ctx, IK_TRACE_RAYS, &h.P);
-        if (h.withTransfer && acc) hipLaunchKernelGGL((k_trace_rays<false, true, true>), dim3(h.blocks), dim3(256), h.ldsBytes, ctx->stream0, h.P);
-        else if (h.withTransfer) hipLaunchKernelGGL((k_trace_rays<false, true, false>), dim3(h.blocks), dim3(256), h.ldsBytes, ctx->stream0, h.P);
-        else if (acc) hipLaunchKernelGGL((k_trace_rays<false, false, true>), dim3(h.blocks), dim3(256), h.ldsBytes, ctx->stream0, h.P);
-        else hipLaunchKernelGGL((k_trace_rays<false, false, false>), dim3(h.blocks), dim3(256), h.ldsBytes, ctx->stream0, h.P);
+        waitShared(ctx, rt_ctx_s::SH_RESULT, st);
+        if (h.P.kwWeightRecalc) waitShared(ctx, rt_ctx_s::SH_TEMPORAL, st);   // (RS:645-657 writes into TemporalFrameBuffer)
+        {
+            LaunchScope ls(ctx, IK_TRACE_RAYS, &h.P, st);
+            if (h.withTransfer && acc) hipLaunchKernelGGL((k_trace_rays<false, true, true>), dim3(h.blocks), dim3(256), h.ldsBytes, st, h.P);
+            else if (h.withTransfer) hipLaunchKernelGGL((k_trace_rays<false, true, false>), dim3(h.blocks), dim3(256), h.ldsBytes, st, h.P);
+            else if (acc) hipLaunchKernelGGL((k_trace_rays<false, false, true>), dim3(h.blocks), dim3(256), h.ldsBytes, st, h.P);
+            else hipLaunchKernelGGL((k_trace_rays<false, false, false>), dim3(h.blocks), dim3(256), h.ldsBytes, st, h.P);
+        }
+        markShared(ctx, rt_ctx_s::SH_RESULT, st);
+        if (h.P.kwWeightRecalc) markShared(ctx, rt_ctx_s::SH_TEMPORAL, st);
     }
 }
 void launchHeld(rt_ctx ctx) { launchHeld(ctx, false); }
@@ -880,7 +1059,7 @@ int dispatchReSTIR(rt_shader sh, int kernel, int gx, int gy) {
             if (lights->stride != 80) return fail(ctx, RT_ERR_INVALID_ARG, "LightObjects stride must be 80");
             P.lights = (const rt_light_object*)lights->dev; P.nLights = lights->count;
             if ((rc = needPlanes(sh, kernel, "HitInfos", LAYOUT_HIT_PLANES, P.hit)) || (rc = checkCount(P.hit, "HitInfos"))) return rc;
-            if ((rc = needRecs(sh, kernel, "Candidates", P.cand)) || (rc = checkCount(P.cand, "Candidates"))) return rc;
+            if ((rc = needRecs(sh, kernel, "Candidates", P.cand, false)) || (rc = checkCount(P.cand, "Candidates"))) return rc;
             if ((rc = needTex(sh, kernel, "DebugOverlay", false, X, Y, P.debugOverlay))) return rc;
             if ((rc = needTex(sh, kernel, "DepthBuffer", true, X, Y, P.depth))) return rc;
             if ((rc = needTex(sh, kernel, "NormalsBuffer", false, X, Y, P.normals))) return rc;
@@ -900,11 +1079,19 @@ int dispatchReSTIR(rt_shader sh, int kernel, int gx, int gy) {
                 SK(ctx);   // (what is held goes first: it was dispatched before this)
                 const Flip flips[3] = {{&bHit->dev, &bHit->alt, layoutBytes(bHit, bHit->layout)}, {&tDepth->dev, &tDepth->alt, tDepth->bytes},
                                        {&tPoints->dev, &tPoints->alt, tPoints->bytes}};
-                beside = mayOverlap(ctx, instr, P) && beginOverlappedPrimary(ctx, flips, 3);
+                // the reservoirs this frame's kernels write: Candidates, and the CandidatesB that SpatialReusePass is bound to
+                rt_buffer bCandB = boundBuffer(sh, 1, "CandidatesB");
+                if (bCandB && (bCandB->layout != LAYOUT_RESERVOIR_RECS || bCandB->count < npx)) bCandB = nullptr;
+                rt_buffer bCand = boundBuffer(sh, kernel, "Candidates");
+                rt_buffer const recs[2] = {bCand, bCandB == bCand ? nullptr : bCandB};
+                beside = mayOverlap(ctx, instr, P) && beginOverlappedPrimary(ctx, flips, 3, recs, 2, true);
                 if (beside) {
                     P.hit = planesOf(bHit);
                     P.depth.r = (float*)tDepth->dev;
                     (P.FrameCount % 2 == 0 ? P.hitA : P.hitB).rgba = (float4*)tPoints->dev;
+                    P.cand = recsOf(recs[0]);
+                } else {
+                    useMainStream(ctx);   // primary rays on the dispatch stream, behind everything
                 }
                 const bool background = beside && ctx->bgGroups > 0 && ctx->bgCounter && blocks > (unsigned)ctx->bgGroups &&
                                         hipMemsetAsync(ctx->bgCounter, 0, 8 * sizeof(uint32_t), ctx->stream1) == hipSuccess;
@@ -916,7 +1103,7 @@ int dispatchReSTIR(rt_shader sh, int kernel, int gx, int gy) {
                     } else if (instr) hipLaunchKernelGGL(k_primary<true>, dim3(blocks), dim3(256), ldsBytes, ls.stream, P);
                     else hipLaunchKernelGGL(k_primary<false>, dim3(blocks), dim3(256), ldsBytes, ls.stream, P);
                 }
-                if (!beside) ctx->mainDirty = true;   // primary rays on stream0: the next overlapped ones follow them
+                if (!beside) { ctx->mainDirty = true; ctx->dirty1 = true; }   // primary rays on stream0: the next overlapped ones follow them
             }
             if (grid && grid->dyn) reorderBlocks(ctx, grid, beside);   // (the primary rays' own table: behind them, on their stream)
             if (beside && (rc = endOverlappedPrimary(ctx))) return rc;
@@ -931,10 +1118,13 @@ int dispatchReSTIR(rt_shader sh, int kernel, int gx, int gy) {
                 ctx->held.kind = 3; ctx->held.P = P; ctx->held.blocks = blocks; ctx->held.ldsBytes = ldsBytes; ctx->held.grid = grid;
                 ctx->held.withTransfer = false;
             } else {
-                LaunchScope ls(ctx, IK_CANDIDATES, &P);
-                if (instr) hipLaunchKernelGGL((k_candidates<true>), dim3(blocks), dim3(256), ldsBytes, ls.stream, P);
-                else hipLaunchKernelGGL((k_candidates<false>), dim3(blocks), dim3(256), ldsBytes, ls.stream, P);
-                markAfterCandidates(ctx);
+                hipStream_t st = SK(ctx);
+                {
+                    LaunchScope ls(ctx, IK_CANDIDATES, &P, st);
+                    if (instr) hipLaunchKernelGGL((k_candidates<true>), dim3(blocks), dim3(256), ldsBytes, st, P);
+                    else hipLaunchKernelGGL((k_candidates<false>), dim3(blocks), dim3(256), ldsBytes, st, P);
+                }
+                markAfterCandidates(ctx, st);
             }
             break;
         }
@@ -995,7 +1185,12 @@ int dispatchReSTIR(rt_shader sh, int kernel, int gx, int gy) {
                     break;
                 }
             }
-            { LaunchScope ls(ctx, IK_TEMPORAL, &P); hipLaunchKernelGGL(k_temporal, dim3(blocks), dim3(256), 0, ls.stream, P); }
+            {
+                hipStream_t st = SK(ctx);
+                waitShared(ctx, rt_ctx_s::SH_TEMPORAL, st);
+                { LaunchScope ls(ctx, IK_TEMPORAL, &P, st); hipLaunchKernelGGL(k_temporal, dim3(blocks), dim3(256), 0, st, P); }
+                markShared(ctx, rt_ctx_s::SH_TEMPORAL, st);
+            }
             break;
         }
         case 4: {  // TraceRays
@@ -1020,9 +1215,16 @@ int dispatchReSTIR(rt_shader sh, int kernel, int gx, int gy) {
                 ctx->held.kind = 2; ctx->held.P = P; ctx->held.blocks = blocks; ctx->held.ldsBytes = ldsBytes; ctx->held.grid = grid;
                 ctx->held.withTransfer = takeCopy;
             } else {
-                LaunchScope ls(ctx, IK_TRACE_RAYS, &P);
-                if (instr) hipLaunchKernelGGL((k_trace_rays<true>), dim3(blocks), dim3(256), ldsBytes, ls.stream, P);
-                else hipLaunchKernelGGL((k_trace_rays<false>), dim3(blocks), dim3(256), ldsBytes, ls.stream, P);
+                hipStream_t st = SK(ctx);
+                waitShared(ctx, rt_ctx_s::SH_RESULT, st);
+                if (P.kwWeightRecalc) waitShared(ctx, rt_ctx_s::SH_TEMPORAL, st);
+                {
+                    LaunchScope ls(ctx, IK_TRACE_RAYS, &P, st);
+                    if (instr) hipLaunchKernelGGL((k_trace_rays<true>), dim3(blocks), dim3(256), ldsBytes, st, P);
+                    else hipLaunchKernelGGL((k_trace_rays<false>), dim3(blocks), dim3(256), ldsBytes, st, P);
+                }
+                markShared(ctx, rt_ctx_s::SH_RESULT, st);
+                if (P.kwWeightRecalc) markShared(ctx, rt_ctx_s::SH_TEMPORAL, st);
             }
             break;
         }
@@ -1092,16 +1294,17 @@ int dispatchRIS(rt_shader sh, int kernel, int gx, int gy) {
             if (grid) P.blockCost = grid->cost;
             // beside the kernels stream0 still holds of the frames before (rt_ctx_s::stream1): the RIS project's primary rays
             // overwrite nothing but HitInfos that those still read
-            SK(ctx);
+            // (one frame stream: the RIS project's Candidates keep their single copy)
+            useMainStream(ctx);
             const Flip flips[1] = {{&hit->dev, &hit->alt, hit->bytes}};
-            beside = mayOverlap(ctx, instr, P) && beginOverlappedPrimary(ctx, flips, 1);
+            beside = mayOverlap(ctx, instr, P) && beginOverlappedPrimary(ctx, flips, 1, nullptr, 0, false);
             if (beside) P.risHit = (rt_ris_hit_info*)hit->dev;
             {
                 LaunchScope ls(ctx, IK_RIS_PRIMARY, &P, beside ? ctx->stream1 : nullptr);
                 if (instr) hipLaunchKernelGGL(k_ris_primary<true>, dim3(blocks), dim3(256), ldsBytes, ls.stream, P);
                 else hipLaunchKernelGGL(k_ris_primary<false>, dim3(blocks), dim3(256), ldsBytes, ls.stream, P);
             }
-            if (!beside) ctx->mainDirty = true;   // primary rays on stream0: the next overlapped ones follow them
+            if (!beside) { ctx->mainDirty = true; ctx->dirty1 = true; }   // primary rays on stream0: the next overlapped ones follow them
         }
         if (grid && grid->dyn) reorderBlocks(ctx, grid, beside);
         if (beside && (rc = endOverlappedPrimary(ctx))) return rc;
@@ -1125,9 +1328,14 @@ int dispatchRIS(rt_shader sh, int kernel, int gx, int gy) {
             ctx->held.kind = 4; ctx->held.P = P; ctx->held.blocks = blocks; ctx->held.ldsBytes = ldsBytes; ctx->held.grid = grid;
             ctx->held.withTransfer = false;
         } else {
-            LaunchScope ls(ctx, IK_RIS_TRACE_RAYS, &P);
-            if (instr) hipLaunchKernelGGL((k_ris_trace_rays<true>), dim3(blocks), dim3(256), ldsBytes, ls.stream, P);
-            else hipLaunchKernelGGL((k_ris_trace_rays<false>), dim3(blocks), dim3(256), ldsBytes, ls.stream, P);
+            hipStream_t st = SK(ctx);
+            waitShared(ctx, rt_ctx_s::SH_RESULT, st);
+            {
+                LaunchScope ls(ctx, IK_RIS_TRACE_RAYS, &P, st);
+                if (instr) hipLaunchKernelGGL((k_ris_trace_rays<true>), dim3(blocks), dim3(256), ldsBytes, st, P);
+                else hipLaunchKernelGGL((k_ris_trace_rays<false>), dim3(blocks), dim3(256), ldsBytes, st, P);
+            }
+            markShared(ctx, rt_ctx_s::SH_RESULT, st);
         }
     }
     return finish(ctx);
@@ -1201,7 +1409,12 @@ int dispatchPostProc(rt_shader sh, int kernel, int gx, int gy) {
             return finish(ctx);
         }
     }
-    if (blocks) { LaunchScope ls(ctx, IK_ACCUMULATE, &P); hipLaunchKernelGGL(k_accumulate, dim3(blocks), dim3(256), 0, ls.stream, P); }
+    if (blocks) {
+        hipStream_t st = SK(ctx);
+        waitShared(ctx, rt_ctx_s::SH_RESULT, st);
+        { LaunchScope ls(ctx, IK_ACCUMULATE, &P, st); hipLaunchKernelGGL(k_accumulate, dim3(blocks), dim3(256), 0, st, P); }
+        markShared(ctx, rt_ctx_s::SH_RESULT, st);
+    }
     return finish(ctx);
 }
 
@@ -1244,11 +1457,16 @@ int rt_create(int device_id, rt_ctx* out) {
         int least = 0, greatest = 0;
         static const bool lowPriority = [] { const char* e = getenv("RT_OVERLAP_PRIORITY"); return e ? atoi(e) != 0 : false; }();
         if (!lowPriority || hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) least = 0;
-        if (hipStreamCreateWithPriority(&ctx->stream1, hipStreamNonBlocking, least) != hipSuccess ||
-            hipEventCreateWithFlags(&ctx->evReaders[0], hipEventDisableTiming) != hipSuccess ||
-            hipEventCreateWithFlags(&ctx->evReaders[1], hipEventDisableTiming) != hipSuccess ||
-            hipEventCreateWithFlags(&ctx->evAfterCandidates, hipEventDisableTiming) != hipSuccess ||
-            hipEventCreateWithFlags(&ctx->evPrimary, hipEventDisableTiming) != hipSuccess) {
+        static const int inFlight = [] { const char* e = getenv("RT_FRAMES_IN_FLIGHT"); return e ? atoi(e) : 2; }();
+        ctx->framesInFlight = inFlight == 1 ? 1 : 2;
+        ctx->frameStream[0] = ctx->stream0;
+        bool ok = hipStreamCreateWithPriority(&ctx->stream1, hipStreamNonBlocking, least) == hipSuccess &&
+                  hipStreamCreateWithFlags(&ctx->frameStream[1], hipStreamNonBlocking) == hipSuccess;
+        std::vector<hipEvent_t*> evs = {&ctx->evAfterCandidates, &ctx->evPrimary, &ctx->evJoin, &ctx->evTail0, &ctx->evOther, &ctx->evTable};
+        for (auto& per : ctx->evShared) for (auto& ev : per) evs.push_back(&ev);
+        for (auto& per : ctx->evSetFree) for (auto& ev : per) evs.push_back(&ev);
+        for (hipEvent_t* ev : evs) ok = ok && hipEventCreateWithFlags(ev, hipEventDisableTiming) == hipSuccess;
+        if (!ok) {
             rt_destroy(ctx);
             return RT_ERR_NO_DEVICE;
         }
@@ -1265,7 +1483,9 @@ int rt_create(int device_id, rt_ctx* out) {
 void rt_destroy(rt_ctx ctx) {
     if (!ctx) return;
     hipError_t e = hipSetDevice(ctx->device);
-    e = hipStreamSynchronize(S(ctx));
+    if (ctx->held.kind) launchHeld(ctx);
+    if (ctx->frameStream[1]) e = hipStreamSynchronize(ctx->frameStream[1]);
+    e = hipStreamSynchronize(ctx->stream0);
     {
         std::lock_guard<std::mutex> lock(scratchMutex);
         for (auto& o : scratchOwner) if (o == ctx) o = nullptr;
@@ -1286,7 +1506,10 @@ void rt_destroy(rt_ctx ctx) {
     for (auto ev : ctx->marks) if (ev) e = hipEventDestroy(ev);
     if (ctx->transferStream) { e = hipStreamSynchronize(ctx->transferStream); e = hipStreamDestroy(ctx->transferStream); }
     if (ctx->stream1) { e = hipStreamSynchronize(ctx->stream1); e = hipStreamDestroy(ctx->stream1); }
-    for (hipEvent_t ev : {ctx->evReaders[0], ctx->evReaders[1], ctx->evPrimary, ctx->evAfterCandidates}) if (ev) e = hipEventDestroy(ev);
+    if (ctx->frameStream[1]) { e = hipStreamSynchronize(ctx->frameStream[1]); e = hipStreamDestroy(ctx->frameStream[1]); }
+    for (hipEvent_t ev : {ctx->evPrimary, ctx->evAfterCandidates, ctx->evJoin, ctx->evTail0, ctx->evOther, ctx->evTable}) if (ev) e = hipEventDestroy(ev);
+    for (auto& per : ctx->evShared) for (hipEvent_t ev : per) if (ev) e = hipEventDestroy(ev);
+    for (auto& per : ctx->evSetFree) for (hipEvent_t ev : per) if (ev) e = hipEventDestroy(ev);
     e = hipStreamDestroy(ctx->stream0);
     (void)e;
     delete ctx;
@@ -1294,7 +1517,14 @@ void rt_destroy(rt_ctx ctx) {
 
 int rt_sync(rt_ctx ctx) {
     if (!ctx) return RT_ERR_INVALID_ARG;
-    HIP_TRY(ctx, hipStreamSynchronize(SK(ctx)));   // (includes the overlapped primary rays: stream0 waits for them)
+    // (the overlapped primary rays are included: the frame streams wait for them)
+    SK(ctx);
+    if (ctx->stream1Pending) {
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->frameStream[1]));
+        ctx->stream1Pending = false;
+    }
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream0));
+    ctx->dirty1 = false;   // nothing is left anywhere that a later launch would have to wait for
     if (ctx->transferStream) HIP_TRY(ctx, hipStreamSynchronize(ctx->transferStream));
     return finish(ctx);
 }
@@ -1343,7 +1573,13 @@ int rt_mark_elapsed(rt_ctx ctx, int a, int b, double* ms) {
     return finish(ctx);
 }
 const char* rt_last_error(rt_ctx ctx) { return ctx ? ctx->err.c_str() : "null context"; }
-void* rt_stream(rt_ctx ctx) { return ctx ? (void*)S(ctx) : nullptr; }
+void* rt_stream(rt_ctx ctx) {
+    if (!ctx) return nullptr;
+    // the host will put work of its own on the stream: from now on every dispatch of this context goes there too
+    useMainStream(ctx);
+    ctx->streamShared = true;
+    return (void*)S(ctx);
+}
 int rt_flush(rt_ctx ctx) {
     if (!ctx) return RT_ERR_INVALID_ARG;
     int rc = useDevice(ctx);
@@ -1360,6 +1596,7 @@ int rt_set_overlap(rt_ctx ctx, int mode) {
     ctx->overlap = processOff ? 0 : mode;   // RT_OVERLAP=0 switches it off for the whole process, whatever is asked for later
     ctx->afterCandidatesValid = false;
     ctx->mainDirty = true;   // the next overlapped primary rays follow all of stream0
+    ctx->dirty1 = true;
     return finish(ctx);
 }
 int rt_set_tuning(rt_ctx ctx, const char* name, int value) {
@@ -1369,7 +1606,14 @@ int rt_set_tuning(rt_ctx ctx, const char* name, int value) {
     SK(ctx);
     if (!strcmp(name, "spatial_lds_max_offset")) ctx->spatialLdsMaxOffset = value < 0 ? 0 : value;
     else if (!strcmp(name, "primary_background_groups")) ctx->bgGroups = value < 0 ? 0 : (value + 7) / 8 * 8;
-    else if (!strcmp(name, "overlap_behind_candidates")) { ctx->behindCandidates = value != 0; ctx->afterCandidatesValid = false; ctx->mainDirty = true; }
+    else if (!strcmp(name, "overlap_behind_candidates")) { ctx->behindCandidates = value != 0; ctx->afterCandidatesValid = false; ctx->mainDirty = true; ctx->dirty1 = true; }
+    else if (!strcmp(name, "frames_in_flight")) {
+        if (value != 1 && value != 2) return fail(ctx, RT_ERR_INVALID_ARG, "frames_in_flight must be 1 or 2");
+        useMainStream(ctx);
+        ctx->framesInFlight = value;
+        if (value == 2) ctx->streamShared = false;   // (the host's word that it no longer uses the stream rt_stream gave it)
+        ctx->mainDirty = true; ctx->dirty1 = true;
+    }
     else return fail(ctx, RT_ERR_INVALID_ARG, "unknown tuning parameter '%s'", name);
     return finish(ctx);
 }
@@ -1461,6 +1705,8 @@ int rt_dispatch_no_alloc(rt_shader sh, int kernel, int gx, int gy, int gz) {
         owner = ctx;
     }
     ctx->noAlloc = true;  // every path below that would allocate (or free) device memory returns an error instead
+    { hipError_t e = hipSetDevice(ctx->device); (void)e; }
+    useMainStream(ctx);   // (enqueues two stream operations at most; allocates nothing)
     int rc = rt_dispatch(sh, kernel, gx, gy, gz);
     ctx->noAlloc = false;
     { hipError_t e = hipEventRecord(ctx->noAllocDone, ctx->stream0); (void)e; }
@@ -1539,6 +1785,7 @@ int rt_buffer_set_data(rt_buffer b, const void* src, size_t bytes) {
     if (bytes > b->bytes) return fail(ctx, RT_ERR_INVALID_ARG, "set_data of %zu bytes into a %zu-byte buffer", bytes, b->bytes);
     int rc = useDevice(ctx);
     if (rc) return rc;
+    if (b->alt && !b->tag) settleRecords(ctx);
     if ((rc = convertLayout(b, LAYOUT_AOS))) return rc;
     // synchronous copy: the caller may reuse `src` as soon as this returns
     HIP_TRY(ctx, hipMemcpyAsync(b->dev, src, bytes, hipMemcpyHostToDevice, S(ctx)));
@@ -1615,6 +1862,7 @@ void rt_buffer_release(rt_buffer b) {
         if (pr.objRoot) e = hipFree(pr.objRoot);
         pr = rt_ctx_s::Prep();
     }
+    if (b->tag) dropTags(b);
     if (b->dev) e = hipFree(b->dev);
     if (b->alt) e = hipFree(b->alt);
     (void)e;
@@ -1668,6 +1916,7 @@ int rt_texture_set_data(rt_texture t, const void* src, size_t bytes) {
         return finish(ctx);
     }
     if (bytes != t->bytes) return fail(ctx, RT_ERR_INVALID_ARG, "texture upload must be %zu bytes", t->bytes);
+    if (t->alt) settleRecords(ctx);
     HIP_TRY(ctx, hipMemcpyAsync(t->dev, src, bytes, hipMemcpyHostToDevice, S(ctx)));
     HIP_TRY(ctx, hipStreamSynchronize(S(ctx)));
     t->version = ctx->versionCounter++;
@@ -1720,6 +1969,13 @@ int rt_buffer_map_rows(rt_buffer b, int width, int row0, int row1, rt_segment ou
         return fail(ctx, RT_ERR_INVALID_ARG, "rows [%d,%d) of width %d are outside the buffer", row0, row1, width);
     SK(ctx);   // whoever reads through these pointers orders itself against the stream: nothing may still be held back
     const size_t first = (size_t)row0 * width, n = (size_t)(row1 - row0) * width;
+    // An object with two copies: the address is that of the current copy.  Unless the context renders row bands beside
+    // one another (overlap 2, where the rows a band does not own are undefined in such objects anyway), that copy is
+    // first made to hold what a single buffer would.
+    if (ctx->overlap != 2) {
+        if (b->tag) mergeRecords(b, (int64_t)first, (int64_t)n);
+        else if (b->alt) settleRecords(ctx);
+    }
     char* base = (char*)b->dev;
     if (b->layout == LAYOUT_AOS) {
         out[0].ptr = base + first * b->stride; out[0].bytes = n * b->stride;
@@ -1734,10 +1990,23 @@ int rt_buffer_map_rows(rt_buffer b, int width, int row0, int row1, rt_segment ou
     }
     return finish(ctx);
 }
+int rt_buffer_rows_written(rt_buffer b, int width, int row0, int row1) {
+    if (!b) return RT_ERR_INVALID_ARG;
+    rt_ctx ctx = b->ctx;
+    if (width < 1 || row0 < 0 || row1 < row0 || (int64_t)row1 * width > b->count)
+        return fail(ctx, RT_ERR_INVALID_ARG, "rows [%d,%d) of width %d are outside the buffer", row0, row1, width);
+    int rc = useDevice(ctx);
+    if (rc) return rc;
+    if (!b->tag || row1 == row0) return finish(ctx);
+    // (only the frames that work on this copy write its tags, and they do so on this stream or behind it)
+    HIP_TRY(ctx, hipMemsetD32Async((hipDeviceptr_t)(b->tag + (size_t)row0 * width), (int)(uint32_t)ctx->epoch, (size_t)(row1 - row0) * width, SK(ctx)));
+    return finish(ctx);
+}
 int rt_texture_map_rows(rt_texture t, int row0, int row1, rt_segment* out) {
     if (!t || !out) return RT_ERR_INVALID_ARG;
     if (row0 < 0 || row1 < row0 || row1 > t->h) return fail(t->ctx, RT_ERR_INVALID_ARG, "rows [%d,%d) are outside the texture", row0, row1);
     SK(t->ctx);
+    if (t->alt && t->ctx->overlap != 2) settleRecords(t->ctx);
     const size_t texel = t->format == RT_FORMAT_R32F ? 4 : 16;
     out->ptr = (char*)t->dev + (size_t)row0 * t->w * texel;
     out->bytes = (size_t)(row1 - row0) * t->w * texel;

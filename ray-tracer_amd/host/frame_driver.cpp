@@ -669,6 +669,8 @@ int rth_mg_loopback(rth_mg g, int src0, int src1, int dst0) {
     int rc2 = rccl().GroupEnd();
     if (rc != 0 || rc2 != 0) { g->err = std::string("RCCL loopback: ") + rccl().GetErrorString(rc != 0 ? rc : rc2); return -1; }
     if (rt_stream_order(ctx, 1) < 0) { g->err = rt_last_error(ctx); return -1; }
+    // (the frame loop never reads halo rows back; a caller of this self-test does)
+    if (rt_buffer_rows_written(m->CandidateBuffer.h, W, dst0, dst0 + (src1 - src0)) < 0) { g->err = rt_last_error(ctx); return -1; }
     return 0;
 }
 

@@ -22,22 +22,31 @@ def snapshot(drv):
     return {**{k: drv.buffer(k) for k in BUFS}, **{k: drv.texture(k) for k in TEXS}}
 
 
-@pytest.mark.parametrize("unorm8", [0, 1])
-def test_overlapped_frames_equal_serial_frames_1080p(gpu_ctx, scene_80k, unorm8):
+@pytest.mark.parametrize("unorm8,in_flight", [(0, 2), (1, 2), (0, 1)])
+def test_overlapped_frames_equal_serial_frames_1080p(gpu_ctx, scene_80k, unorm8, in_flight):
     cfg = rt.default_config()
     cfg.Unorm8RenderTargets = unorm8
     frames = 7   # odd: the last frame leaves the buffers on their second copies
     try:
+        gpu_ctx.set_tuning("frames_in_flight", in_flight)
         gpu_ctx.set_overlap(0)
+        pos = np.array(cfg.cameraPosition[:], np.float32)
+        rot = [float(x) for x in cfg.cameraRotation]
+
+        def move(drv, f):   # a camera that drifts and turns: hit pixels come and go, TemporalReuse reprojects
+            drv.set_camera(pos + np.float32(0.01 * f) * np.array([1, 0.2, 0.5], np.float32), [rot[0] + 0.7 * f, rot[1] - 1.1 * f, rot[2]])
+
         serial = rt.Driver(gpu_ctx, cfg, scene_80k)
-        for _ in range(frames):
+        for f in range(frames):
+            move(serial, f)
             serial.render_frame()
         want = snapshot(serial)
         serial.close()
         gpu_ctx.set_overlap(1)
         beside = rt.Driver(gpu_ctx, cfg, scene_80k)
-        for _ in range(frames):
-            beside.render_frame()          # no call in between: frame f+1's primary rays meet frame f's kernels
+        for f in range(frames):
+            move(beside, f)
+            beside.render_frame()          # no call in between: frame f+1's kernels meet frame f's
         got = snapshot(beside)
         beside.close()
         for k in want:
@@ -45,6 +54,7 @@ def test_overlapped_frames_equal_serial_frames_1080p(gpu_ctx, scene_80k, unorm8)
         assert np.isfinite(got["DepthBuffer"]).sum() > 0.1 * got["DepthBuffer"].size
     finally:
         gpu_ctx.set_overlap(1)
+        gpu_ctx.set_tuning("frames_in_flight", 2)
 
 
 def test_reads_between_the_dispatches_of_consecutive_frames(gpu_ctx, scene_small):
@@ -96,6 +106,13 @@ def test_unsynchronised_frames_against_the_oracle(gpu_ctx, scene_small):
             p = pos + np.float32(0.002 * f) * np.array([1, 0, 0.5], np.float32)
             drv.set_camera(p, rot); orc.set_camera(p, rot)
             drv.render_frame(); orc.render_frame()
+        # then the camera turns away: pixels that held a hit keep the reservoirs of the last frame that hit them, which
+        # by then live in one or the other of the two copies the frames in flight alternate between
+        for f in range(3):
+            r = [rot[0] - 25.0 * (f + 1), rot[1] + 40.0 * (f + 1), rot[2]]
+            drv.set_camera(pos, r); orc.set_camera(pos, r)
+            drv.render_frame(); orc.render_frame()
+        assert (~np.isfinite(orc.tex["DepthBuffer"])).sum() > 0.2 * orc.tex["DepthBuffer"].size
         for k in BUFS:
             assert np.array_equal(h.bits(drv.buffer(k)), h.bits(orc.buf[k])), k
         for k in TEXS:
@@ -178,3 +195,77 @@ def test_speed_only_choices_leave_every_bit_alone(gpu_ctx, scene_small, name, va
     finally:
         for n, v in (("spatial_lds_max_offset", 0), ("primary_background_groups", 0), ("overlap_behind_candidates", 1)):
             gpu_ctx.set_tuning(n, v)
+
+
+def test_two_drivers_taking_turns_on_one_context(gpu_ctx, scene_small):
+    """Frames of two frame loops enqueued alternately, and two in a row: each loop's frames equal the frames it renders
+    on its own (the copies and streams the frames alternate between belong to the context, the buffers to the loops)."""
+    cfg_a, cfg_b = h.small_config(136, 96), h.small_config(96, 136)
+    order = "ababbaabab"
+    want = {}
+    for name, cfg in (("a", cfg_a), ("b", cfg_b)):
+        alone = rt.Driver(gpu_ctx, cfg, scene_small)
+        for _ in range(order.count(name)):
+            alone.render_frame()
+        want[name] = snapshot(alone)
+        alone.close()
+    drv = {"a": rt.Driver(gpu_ctx, cfg_a, scene_small), "b": rt.Driver(gpu_ctx, cfg_b, scene_small)}
+    try:
+        for name in order:
+            drv[name].render_frame()
+        for name in "ab":
+            got = snapshot(drv[name])
+            for k in got:
+                assert np.array_equal(h.bits(want[name][k]), h.bits(got[k])), f"{name}: {k}"
+    finally:
+        for d in drv.values():
+            d.close()
+
+
+def test_uploads_between_frames_in_flight(gpu_ctx, scene_small):
+    """A host that reads a per-pixel object back and uploads it again between frames changes nothing: the reservoirs come
+    back merged from their two copies, the upload makes one copy of them, and the frames go on alternating."""
+    cfg = h.small_config(152, 104)
+    plain, busy = rt.Driver(gpu_ctx, cfg, scene_small), rt.Driver(gpu_ctx, cfg, scene_small)
+    try:
+        pos = np.array(cfg.cameraPosition[:], np.float32)
+        rot = [float(x) for x in cfg.cameraRotation]
+        for f in range(7):
+            r = [rot[0] - 12.0 * f, rot[1] + 15.0 * f, rot[2]]
+            for d in (plain, busy):
+                d.set_camera(pos, r)
+            plain.render_frame()
+            busy.render_frame()
+            if f == 2:
+                gpu_ctx.set_buffer_data(busy.buffer_handle("Candidates"), busy.buffer("Candidates"))
+            if f == 3:
+                gpu_ctx.set_buffer_data(busy.buffer_handle("HitInfos"), busy.buffer("HitInfos"))
+            if f == 4:
+                depth = np.ascontiguousarray(busy.texture("DepthBuffer"))
+                gpu_ctx.check(gpu_ctx.lib.rt_texture_set_data(busy.texture_handle("DepthBuffer"), depth.ctypes.data, depth.nbytes), "rt_texture_set_data")
+            if f == 5:
+                gpu_ctx.buffer_rows(busy.buffer_handle("CandidatesB"), cfg.Resolution[0], 8, 40)
+        want, got = snapshot(plain), snapshot(busy)
+        for k in want:
+            assert np.array_equal(h.bits(want[k]), h.bits(got[k])), k
+    finally:
+        plain.close()
+        busy.close()
+
+
+def test_weight_recalc_orders_the_frames_in_flight(gpu_ctx, scene_small):
+    """WEIGHT_RECALC: TraceRays writes into TemporalFrameBuffer (ReSTIR_BVH_RayTracer.compute:645-657), which the next
+    frame's TemporalReuse reads: the next frame's reuse then has to wait for it."""
+    cfg = h.small_config(168, 96)
+    cfg.DoWeightRecalc = 1
+    drv = rt.Driver(gpu_ctx, cfg, scene_small)
+    orc = h.OracleRenderer(scene_small.arrays(), cfg)
+    try:
+        for _ in range(5):
+            drv.render_frame(); orc.render_frame()
+        for k in BUFS:
+            assert np.array_equal(h.bits(drv.buffer(k)), h.bits(orc.buf[k])), k
+        for k in TEXS:
+            assert np.array_equal(h.bits(drv.texture(k)), h.bits(orc.tex[k])), k
+    finally:
+        drv.close()

@@ -209,4 +209,5 @@ def test_flush_launches_what_is_held(gpu_ctx, scene_small):
         assert np.array_equal(h.bits(raw_result()), h.bits(orc.tex["Result"]))
     finally:
         gpu_ctx.set_fusion(True)
+        gpu_ctx.set_tuning("frames_in_flight", 2)   # (this test no longer uses the stream it took: frames may alternate again)
         drv.close()

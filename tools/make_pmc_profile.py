@@ -2,7 +2,7 @@
 """Turns the rocprofv3 --pmc pass summaries of tools/collect_profiles.sh into profiles/r02_pmc.json: per kernel of the
 benchmark frame, the HBM bytes per launch and the occupancy figures bench.py quotes next to its timings.
 
-    python tools/make_pmc_profile.py gpurun_out > profiles/r02_pmc.json
+    python tools/make_pmc_profile.py gpurun_out/pmc_<tag> [bench.py arguments of the passes] > profiles/r03_pmc_<tag>.json
 
 FETCH_SIZE and WRITE_SIZE are reported in KiB; on gfx950 FETCH_SIZE tallies 128-byte requests at 64 bytes, so
 bytes = FETCH_SIZE x 1024 x 2 + WRITE_SIZE x 1024 (checked on k_accumulate, whose 48 bytes per pixel are known).
@@ -19,7 +19,8 @@ sys.path.insert(0, ROOT)
 import bench  # noqa: E402  (source_hash)
 
 NAMES = {"k_primary": "primary", "k_candidates": "candidates", "k_trace_rays": "trace_rays", "k_temporal": "temporal",
-         "k_spatial": "spatial", "k_transfer": "transfer", "k_accumulate": "accumulate"}
+         "k_spatial": "spatial", "k_transfer": "transfer", "k_accumulate": "accumulate",
+         "k_ris_primary": "ris_primary", "k_ris_candidates": "ris_candidates", "k_ris_trace_rays": "ris_trace_rays"}
 CUS, SIMDS, XCDS = 256, 1024, 8
 
 
@@ -37,12 +38,25 @@ def read(path):
     return out
 
 
-d = sys.argv[1]
-fetch, write = read(f"{d}/pmc_fetch_summary.txt"), read(f"{d}/pmc_write_summary.txt")
-sq, ta = read(f"{d}/pmc_sq_summary.txt"), read(f"{d}/pmc_ta_summary.txt")
+import argparse  # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument("dir")
+ap.add_argument("--width", type=int, default=1920)
+ap.add_argument("--height", type=int, default=1080)
+ap.add_argument("--scene", default="80k")
+ap.add_argument("--project", default="restir")
+ap.add_argument("--small-scene", action="store_true")
+args, _ = ap.parse_known_args()
+d = args.dir
+fetch, write = read(f"{d}/fetch_summary.txt"), read(f"{d}/write_summary.txt")
+sq, ta = read(f"{d}/sq_summary.txt"), read(f"{d}/ta_summary.txt")
+tcc = read(f"{d}/tcc_summary.txt") if os.path.exists(f"{d}/tcc_summary.txt") else {}
 kernels = {}
 for name in fetch:
     k = {"FETCH_SIZE_KiB": fetch[name]["FETCH_SIZE"], "WRITE_SIZE_KiB": write.get(name, {}).get("WRITE_SIZE", 0.0)}
+    k["hbm_fetch_MB_per_launch"] = k["FETCH_SIZE_KiB"] * 1024 * 2 / 1e6
+    k["hbm_write_MB_per_launch"] = k["WRITE_SIZE_KiB"] * 1024 / 1e6
     k["hbm_bytes_per_launch"] = k["FETCH_SIZE_KiB"] * 1024 * 2 + k["WRITE_SIZE_KiB"] * 1024
     if name in sq and name in ta:
         s, t = sq[name], ta[name]
@@ -55,9 +69,12 @@ for name in fetch:
         k["l1_accesses_per_launch"] = t["TCP_TOTAL_CACHE_ACCESSES_sum"]
         k["l1_accesses_per_cu_clk"] = t["TCP_TOTAL_CACHE_ACCESSES_sum"] / (cycles * CUS)
         k["l1_hit_frac"] = 1.0 - t["TCP_TCC_READ_REQ_sum"] / t["TCP_TOTAL_CACHE_ACCESSES_sum"]
+    if name in tcc and tcc[name].get("TCC_REQ_sum"):
+        k["l2_hit_frac"] = tcc[name]["TCC_HIT_sum"] / (tcc[name]["TCC_HIT_sum"] + tcc[name]["TCC_MISS_sum"])
+        k["l2_requests_per_launch"] = tcc[name]["TCC_REQ_sum"]
     kernels[name] = k
-json.dump({"workload": "bench.py defaults under rocprofv3 --pmc, one pass per counter group (tools/collect_profiles.sh)",
-           "config": {"width": 1920, "height": 1080, "world": 1, "small_scene": False, "scene": "80k", "project": "restir"},
+json.dump({"workload": "bench.py with the arguments of `config` under rocprofv3 --pmc, one pass per counter group (tools/collect_profiles.sh)",
+           "config": {"width": args.width, "height": args.height, "world": 1, "small_scene": args.small_scene, "scene": args.scene, "project": args.project},
            "source_hash": bench.source_hash(),
            "correction": "hbm bytes = FETCH_SIZE*1024*2 + WRITE_SIZE*1024 (gfx950: FETCH_SIZE counts 128-byte requests at 64 bytes)",
            "kernels": kernels}, sys.stdout, indent=1)

@@ -1,12 +1,20 @@
 #!/bin/bash
 # Copies what tools/collect_profiles.sh left under gpurun_out/ into profiles/ (tracked), named for this round.
 set -e
-R=r02
+R=r03
 cp "$(ls -t gpurun_out/ktrace/*/*_kernel_stats.csv | head -1)" profiles/${R}_kernel_stats.csv
-cat gpurun_out/pmc_fetch_summary.txt gpurun_out/pmc_write_summary.txt gpurun_out/pmc_sq_summary.txt gpurun_out/pmc_ta_summary.txt gpurun_out/pmc_tcc_summary.txt > profiles/${R}_pmc_summary.txt
-python3 tools/make_pmc_profile.py gpurun_out > profiles/${R}_pmc.json
+[ -d gpurun_out/ktrace_unique4k ] && cp "$(ls -t gpurun_out/ktrace_unique4k/*/*_kernel_stats.csv | head -1)" profiles/${R}_kernel_stats_unique_4k.csv
+[ -d gpurun_out/ktrace_ris ] && cp "$(ls -t gpurun_out/ktrace_ris/*/*_kernel_stats.csv | head -1)" profiles/${R}_kernel_stats_ris.csv
+pub() {   # <tag> [make_pmc_profile arguments]
+    tag=$1; shift
+    [ -d gpurun_out/pmc_$tag ] || return 0
+    cat gpurun_out/pmc_$tag/*_summary.txt > profiles/${R}_pmc_summary_$tag.txt
+    python3 tools/make_pmc_profile.py gpurun_out/pmc_$tag "$@" > profiles/${R}_pmc_$tag.json
+}
+pub restir_80k_1920x1080
+pub restir_unique_3840x2160 --scene unique --width 3840 --height 2160
+pub ris_80k_1920x1080 --project ris
 cp gpurun_out/bench_final.json profiles/${R}_bench.json
 cp gpurun_out/bench_under_rocprof.json profiles/${R}_bench_under_rocprof.json
-for n in 4k ris instanced_4k unique_4k; do cp gpurun_out/bench_$n.json profiles/${R}_bench_$n.json; done
-[ -f gpurun_out/bench_256.json ] && cp gpurun_out/bench_256.json profiles/${R}_bench_256.json
+for n in 4k ris instanced_4k unique_4k 256; do [ -f gpurun_out/bench_$n.json ] && cp gpurun_out/bench_$n.json profiles/${R}_bench_$n.json; done
 ls -la profiles/

@@ -1,0 +1,58 @@
+"""What a scene reload costs (Main.Update -> UpdateSettings(true) -> SetData, Main.cs:117-132, 273-310): one object
+moves, the host rebuilds the scene level, the driver releases and re-creates all ten buffers, uploads the scene again,
+runs CalcTriNormals, and the first InitialTrace after it rebuilds the library's traversal arrays.
+
+    python tools/reload_cost.py [80k|instanced|unique] [width height]
+"""
+import importlib
+import json
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+rt = importlib.import_module("ray-tracer_amd")
+which = sys.argv[1] if len(sys.argv) > 1 else "80k"
+W, H = (int(sys.argv[2]), int(sys.argv[3])) if len(sys.argv) > 3 else (1920, 1080)
+t0 = time.perf_counter()
+scene = rt.build_scene_s0(subdivide=True) if which == "80k" else rt.build_scene_instanced(unique=which == "unique")
+build_s = time.perf_counter() - t0
+cfg = rt.default_config()
+cfg.Resolution[0], cfg.Resolution[1] = W, H
+ctx = rt.RtContext(0)
+drv = rt.Driver(ctx, cfg, scene)
+for _ in range(4):
+    drv.render_frame()
+ctx.sync()
+a = scene.arrays()
+out = {"scene": which, "resolution": [W, H], "triangles": len(a["Triangles"]), "bv_nodes": len(a["BVs"]), "objects": len(a["SceneObjects"]),
+       "first_build_host_s": build_s, "reloads": []}
+for k in range(3):
+    step = {}
+    t = time.perf_counter()
+    scene.set_object_transform(1, (-3.0 + 0.1 * k, -2.0, 12.0), (0.0, 25.0 + k, 0.0), (12.0, 12.0, 12.0))
+    scene.rebuild()
+    step["host_rebuild_ms"] = (time.perf_counter() - t) * 1e3
+    drv.reload()
+    t = time.perf_counter()
+    drv.update_per_frame()          # UpdatePerFrame + UpdateSettings(true): release, create, upload, CalcTriNormals
+    ctx.sync()
+    step["set_data_ms"] = (time.perf_counter() - t) * 1e3
+    t = time.perf_counter()
+    drv.run_stage(0)                # InitialTrace: the traversal arrays are validated and rebuilt first
+    ctx.sync()
+    step["first_initial_trace_ms"] = (time.perf_counter() - t) * 1e3
+    t = time.perf_counter()
+    for s in (1, 2, 3):
+        drv.run_stage(s)
+    drv.run_post_processing()
+    ctx.sync()
+    step["rest_of_frame_ms"] = (time.perf_counter() - t) * 1e3
+    t = time.perf_counter()
+    drv.render_frame()
+    ctx.sync()
+    step["next_frame_ms"] = (time.perf_counter() - t) * 1e3
+    out["reloads"].append({k2: round(v, 3) for k2, v in step.items()})
+print(json.dumps(out))
+drv.close()
+ctx.close()
