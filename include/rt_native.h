@@ -261,6 +261,12 @@ int rt_stream_order(rt_ctx ctx, int first);
  * (0 or 1); rt_mark_elapsed waits for both stamps and returns the milliseconds from stamp a to stamp b. */
 int rt_mark(rt_ctx ctx, int stream, int slot);
 int rt_mark_elapsed(rt_ctx ctx, int slot_a, int slot_b, double* milliseconds);
+/* A stamp as an ordering point: whatever is enqueued LATER on `stream` (0 = the dispatch stream of the frame being
+ * dispatched, 1 = the transfer stream) starts only when the work that preceded the last rt_mark of `slot` is done.
+ * Unlike rt_stream_order the point waited for need not be the present end of the other stream: a multi-GPU host
+ * stamps the end of frame f, goes on enqueueing frame f+1, and later lets the gather of frame f wait for the stamp.
+ * Fails with RT_ERR_INVALID_ARG for a slot that was never stamped.  Nothing blocks on the host. */
+int rt_wait_mark(rt_ctx ctx, int stream, int slot);
 
 /* ---- measurement (no counterpart in the reference) -------------------------------------------------------- */
 

@@ -75,6 +75,7 @@ internal static class RtNative
     [DllImport(Lib)] public static extern IntPtr rt_transfer_stream(IntPtr ctx);
     [DllImport(Lib)] public static extern int rt_stream_order(IntPtr ctx, int first);
     [DllImport(Lib)] public static extern int rt_mark(IntPtr ctx, int stream, int slot);
+    [DllImport(Lib)] public static extern int rt_wait_mark(IntPtr ctx, int stream, int slot);
     [DllImport(Lib)] public static extern int rt_mark_elapsed(IntPtr ctx, int slotA, int slotB, out double milliseconds);
 
     // measurement

@@ -65,7 +65,7 @@ def native_lib():
             "rt_create": (ci, [ci, C.POINTER(vp)]), "rt_destroy": (None, [vp]), "rt_sync": (ci, [vp]),
             "rt_last_error": (cs, [vp]), "rt_stream": (vp, [vp]), "rt_transfer_stream": (vp, [vp]),
             "rt_flush": (ci, [vp]), "rt_set_fusion": (ci, [vp, ci]), "rt_set_overlap": (ci, [vp, ci]), "rt_set_tuning": (ci, [vp, cs, ci]),
-            "rt_stream_order": (ci, [vp, ci]), "rt_mark": (ci, [vp, ci, ci]), "rt_mark_elapsed": (ci, [vp, ci, ci, C.POINTER(C.c_double)]), "rt_set_row_band": (ci, [vp, ci, ci]),
+            "rt_stream_order": (ci, [vp, ci]), "rt_mark": (ci, [vp, ci, ci]), "rt_wait_mark": (ci, [vp, ci, ci]), "rt_mark_elapsed": (ci, [vp, ci, ci, C.POINTER(C.c_double)]), "rt_set_row_band": (ci, [vp, ci, ci]),
             "rt_shader_open": (ci, [vp, cs, C.POINTER(vp)]), "rt_shader_close": (None, [vp]),
             "rt_find_kernel": (ci, [vp, cs]), "rt_dispatch": (ci, [vp, ci, ci, ci, ci]),
             "rt_dispatch_no_alloc": (ci, [vp, ci, ci, ci, ci]),
@@ -210,6 +210,7 @@ def host_lib():
             "rth_mg_set_bounds": (ci, [vp, C.POINTER(ci)]), "rth_mg_row_costs": (ci, [vp, C.POINTER(C.c_double)]),
             "rth_mg_balance": (ci, [vp]), "rth_mg_enable_timing": (ci, [vp, ci]),
             "rth_mg_times": (ci, [vp, C.POINTER(C.c_double)]), "rth_mg_halo_plan": (ci, [ci, ci, C.POINTER(ci), C.POINTER(ci)]),
+            "rth_hub_create": (vp, [ci]), "rth_hub_destroy": (None, [vp]), "rth_mg_use_hub": (ci, [vp, vp]),
             "rth_mg_unique_id": (ci, [C.c_char_p]), "rth_mg_create": (vp, [vp, ci, ci, C.POINTER(ci), C.c_char_p, C.c_char_p, ci]),
             "rth_mg_destroy": (None, [vp]), "rth_mg_last_error": (cs, [vp]), "rth_mg_bounds": (ci, [vp, C.POINTER(ci)]),
             "rth_mg_render_frames": (ci, [vp, ci]), "rth_mg_loopback": (ci, [vp, ci, ci, ci]),

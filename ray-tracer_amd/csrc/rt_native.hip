@@ -318,6 +318,7 @@ void waitShared(rt_ctx ctx, int object, hipStream_t stream) {
     if (ctx->sharedValid[object][other]) { hipError_t e = hipStreamWaitEvent(stream, ctx->evShared[object][other], 0); (void)e; }
 }
 void markShared(rt_ctx ctx, int object, hipStream_t stream) {
+    if (ctx->framesInFlight < 2 || ctx->streamShared) { ctx->sharedValid[object][ctx->cur] = false; return; }
     ctx->sharedValid[object][ctx->cur] = hipEventRecord(ctx->evShared[object][ctx->cur], stream) == hipSuccess;
 }
 // The stream of the frame being dispatched waits for all the other frame stream holds.
@@ -1558,6 +1559,15 @@ int rt_mark(rt_ctx ctx, int stream, int slot) {
     if (stream == 1 && !rt_transfer_stream(ctx)) return RT_ERR_NO_DEVICE;
     if (!ctx->marks[slot]) HIP_TRY(ctx, hipEventCreate(&ctx->marks[slot]));
     HIP_TRY(ctx, hipEventRecord(ctx->marks[slot], stream == 0 ? SK(ctx) : ctx->transferStream));
+    return finish(ctx);
+}
+int rt_wait_mark(rt_ctx ctx, int stream, int slot) {
+    if (!ctx || stream < 0 || stream > 1 || slot < 0 || slot >= 64) return RT_ERR_INVALID_ARG;
+    if (!ctx->marks[slot]) return fail(ctx, RT_ERR_INVALID_ARG, "stamp %d was never recorded", slot);
+    int rc = useDevice(ctx);
+    if (rc) return rc;
+    if (stream == 1 && !rt_transfer_stream(ctx)) return RT_ERR_NO_DEVICE;
+    HIP_TRY(ctx, hipStreamWaitEvent(stream == 0 ? SK(ctx) : ctx->transferStream, ctx->marks[slot], 0));
     return finish(ctx);
 }
 int rt_mark_elapsed(rt_ctx ctx, int a, int b, double* ms) {

@@ -436,19 +436,24 @@ rt_shader rth_main_shader(rth_main m, const char* name) {
 // The schedule is the one ray-tracer_amd/multigpu.py runs over torch.distributed (and that the CPU tests check
 // against the single-process result); here no Python runs between frames.
 //
-// Streams.  Kernels run on the context's dispatch stream, all transfers on its transfer stream (rt_transfer_stream),
-// with ONE communicator: every rank enqueues the same sequence of grouped send/recv calls on that one stream
-// (halo f, gather f, halo f+1, ...), which is the ordering RCCL asks for.  Per frame:
+// Streams.  Kernels run on the context's dispatch streams (the library alternates consecutive frames between two), all
+// transfers on its transfer stream (rt_transfer_stream), with ONE communicator: every rank enqueues the same sequence
+// of grouped send/recv calls on that one stream (halo 0, halo 1, gather 0, halo 2, gather 1, ...; with the per-step
+// timing on: halo f, gather f, halo f+1, ... - so the timing switch must be the same on every rank), which is the
+// ordering RCCL asks for.  Per frame:
 //   dispatch stream : InitialTrace, TemporalReuse | pass 0 on the interior rows | pass 0 on the border rows, later
 //                     passes, TransferToOriginal | TraceRays, AccumulateFrames
-//   transfer stream :                             | halo exchange ............ |        | gather of Result (overlaps
-//                                                                                          the next frame's InitialTrace)
+//   transfer stream :                             | halo exchange, then the gather of the frame before ...
 // The interior rows of the first pass read nothing a neighbour owns, so they run while the halos travel; TraceRays
 // of frame f+1 is the first kernel that writes what gather f reads (this rank's band of Result) and waits for it.
 // ==================================================================================================================
 #include <dlfcn.h>
 
 #include <algorithm>
+#include <condition_variable>
+#include <deque>
+#include <memory>
+#include <mutex>
 
 namespace {
 
@@ -486,16 +491,61 @@ struct Rccl {
     }
 };
 Rccl& rccl() { static Rccl r; return r; }
+// The few HIP runtime calls the rehearsal transport below makes, resolved at run time like RCCL's (this library is
+// plain C++ and otherwise reaches the GPU only through the C-ABI).
+struct HipRt {
+    int (*SetDevice)(int) = nullptr;
+    int (*EventCreateWithFlags)(void**, unsigned) = nullptr;
+    int (*EventRecord)(void*, void*) = nullptr;
+    int (*EventDestroy)(void*) = nullptr;
+    int (*StreamWaitEvent)(void*, void*, unsigned) = nullptr;
+    int (*MemcpyAsync)(void*, const void*, size_t, int, void*) = nullptr;
+    bool ok = false;
+    HipRt() {
+        void* h = nullptr;
+        for (const char* name : {"libamdhip64.so", "libamdhip64.so.7", "/opt/rocm/lib/libamdhip64.so"})
+            if ((h = dlopen(name, RTLD_NOW | RTLD_GLOBAL))) break;
+        if (!h) return;
+        bool all = true;
+        auto sym = [&](const char* n) { void* p = dlsym(h, n); all = all && p; return p; };
+        SetDevice = (decltype(SetDevice))sym("hipSetDevice");
+        EventCreateWithFlags = (decltype(EventCreateWithFlags))sym("hipEventCreateWithFlags");
+        EventRecord = (decltype(EventRecord))sym("hipEventRecord");
+        EventDestroy = (decltype(EventDestroy))sym("hipEventDestroy");
+        StreamWaitEvent = (decltype(StreamWaitEvent))sym("hipStreamWaitEvent");
+        MemcpyAsync = (decltype(MemcpyAsync))sym("hipMemcpyAsync");
+        ok = all;
+    }
+};
+HipRt& hipRt() { static HipRt r; return r; }
 const int NCCL_UINT8 = 1;   // ncclUint8
 const int NCCL_DOUBLE = 8;  // ncclFloat64
 const int NCCL_SUM = 0;
 
 // stamps (rt_mark slots) of one frame, for the per-rank breakdown
-enum { MK_FRAME = 0, MK_PRE, MK_INTERIOR, MK_HALO0, MK_HALO1, MK_POST0, MK_END, MK_GATHER0, MK_GATHER1 };
+enum { MK_FRAME = 0, MK_PRE, MK_INTERIOR, MK_HALO0, MK_HALO1, MK_POST0, MK_END, MK_GATHER0, MK_GATHER1,
+       // ordering points of the frame loop (rt_wait_mark)
+       MK_HALO_DONE = 16, MK_FRAME_END, MK_GATHER_DONE };
 
 }  // namespace
 
+// Rehearsal transport: the ranks of a frame loop as THREADS of one process whose contexts share one GPU - the one case
+// RCCL refuses - so that rth_mg_render_frames itself (its order of halo exchanges and gathers, its waits) can be run
+// and checked on a single GPU.  Same contract as RCCL's grouped point-to-point calls: the k-th send of rank a to rank
+// b meets the k-th receive of b from a; a transfer starts when both transfer streams have reached it and both streams
+// go on when it is done.  Carried out as a device copy on the receiver's stream between two events; the host threads
+// meet at every group (a receive blocks until its send is posted, a group ends when its sends are taken).
+struct rth_hub_s {
+    struct SendRec { const void* ptr; size_t bytes; void* ready; void* copied = nullptr; bool taken = false; };
+    int world = 0;
+    std::mutex mu;
+    std::condition_variable cv;
+    std::vector<std::deque<std::shared_ptr<SendRec>>> queue;   // [src * world + dst]
+    bool broken = false;   // a rank gave up: nobody waits any longer
+};
+
 struct rth_mg_s {
+    rth_hub_s* hub = nullptr;    // rehearsal transport instead of a communicator
     rth_main m = nullptr;        // the ReSTIR driver, or
     rth_ris_main ris = nullptr;  // the RIS driver (no cross-pixel reads: no halo, only the gather)
     rt_ctx ctx = nullptr;
@@ -504,6 +554,8 @@ struct rth_mg_s {
     std::vector<int> bounds;
     Rccl::comm_t comm = nullptr;
     bool timing = false;
+    bool gatherPending = false;   // a frame has ended whose gather is not enqueued yet
+    bool gatherStamped = false;   // MK_GATHER_DONE has been recorded
     double sums[RTH_MG_TIMES] = {};
     int timedFrames = 0;
     std::string err;
@@ -619,6 +671,22 @@ rth_mg rth_mg_create_ris(rth_ris_main m, int rank, int world, const int* bounds,
         g->W = res[0]; g->H = res[1];
     }
     return mgCreate(g, rank, world, bounds, uniqueId, err, errLen);
+}
+rth_hub rth_hub_create(int world) {
+    if (world < 1 || !hipRt().ok) return nullptr;
+    rth_hub_s* hub = new rth_hub_s;
+    hub->world = world;
+    hub->queue.resize((size_t)world * world);
+    return hub;
+}
+void rth_hub_destroy(rth_hub hub) { delete hub; }
+int rth_mg_use_hub(rth_mg g, rth_hub hub) {
+    if (!g || !hub) return -1;
+    if (g->comm) { g->err = "this rank already has a communicator"; return -1; }
+    if (hub->world != g->world) { g->err = "the hub was made for another number of ranks"; return -1; }
+    if (!rt_transfer_stream(g->ctx)) { g->err = rt_last_error(g->ctx); return -1; }
+    g->hub = hub;
+    return 0;
 }
 void rth_mg_destroy(rth_mg g) {
     if (!g) return;
@@ -794,8 +862,59 @@ void mgPhase(rth_mg g, int phase) {
     }
 }
 // Enqueues the transfers of `plan` as one RCCL group on the transfer stream.
+void hubRun(rth_mg g, const std::vector<rth_xfer>& plan) {
+    rth_hub_s* hub = g->hub;
+    HipRt& hip = hipRt();
+    void* stream = rt_transfer_stream(g->ctx);
+    if (!stream) throw DriverError{rt_last_error(g->ctx)};
+    auto check = [&](int rc, const char* what) { if (rc != 0) { { std::lock_guard<std::mutex> l(hub->mu); hub->broken = true; } hub->cv.notify_all(); throw DriverError{std::string(what) + " failed in the rehearsal transport"}; } };
+    const int me = g->rank, world = hub->world;
+    std::vector<std::shared_ptr<rth_hub_s::SendRec>> mine;
+    // the sends first: what precedes this group on the transfer stream is what the receiver has to wait for
+    for (const auto& x : plan) {
+        if (!x.send) continue;
+        auto rec = std::make_shared<rth_hub_s::SendRec>();
+        rec->ptr = x.ptr; rec->bytes = x.bytes;
+        check(hip.EventCreateWithFlags(&rec->ready, 2 /* hipEventDisableTiming */), "hipEventCreate");
+        check(hip.EventRecord(rec->ready, stream), "hipEventRecord");
+        { std::lock_guard<std::mutex> l(hub->mu); hub->queue[(size_t)me * world + x.peer].push_back(rec); }
+        mine.push_back(rec);
+    }
+    hub->cv.notify_all();
+    for (const auto& x : plan) {
+        if (x.send) continue;
+        std::shared_ptr<rth_hub_s::SendRec> rec;
+        {
+            std::unique_lock<std::mutex> l(hub->mu);
+            auto& q = hub->queue[(size_t)x.peer * world + me];
+            hub->cv.wait(l, [&] { return hub->broken || !q.empty(); });
+            if (hub->broken) throw DriverError{"another rank of the rehearsal gave up"};
+            rec = q.front();
+            q.pop_front();
+        }
+        if (rec->bytes != x.bytes) check(1, "matching a send of another size");
+        check(hip.StreamWaitEvent(stream, rec->ready, 0), "hipStreamWaitEvent");
+        check(hip.MemcpyAsync(x.ptr, rec->ptr, x.bytes, 3 /* hipMemcpyDeviceToDevice */, stream), "hipMemcpyAsync");
+        void* copied = nullptr;
+        check(hip.EventCreateWithFlags(&copied, 2), "hipEventCreate");
+        check(hip.EventRecord(copied, stream), "hipEventRecord");
+        { std::lock_guard<std::mutex> l(hub->mu); rec->copied = copied; rec->taken = true; }
+        hub->cv.notify_all();
+    }
+    for (auto& rec : mine) {   // the sender's stream goes on when its rows have been copied out
+        {
+            std::unique_lock<std::mutex> l(hub->mu);
+            hub->cv.wait(l, [&] { return hub->broken || rec->taken; });
+            if (hub->broken) throw DriverError{"another rank of the rehearsal gave up"};
+        }
+        check(hip.StreamWaitEvent(stream, rec->copied, 0), "hipStreamWaitEvent");
+        hip.EventDestroy(rec->ready);    // (released by the runtime once the work that refers to them is done)
+        hip.EventDestroy(rec->copied);
+    }
+}
 void mgRun(rth_mg g, const std::vector<rth_xfer>& plan) {
     if (plan.empty()) return;
+    if (g->hub) return hubRun(g, plan);
     auto nccl = [&](int rc, const char* what) { if (rc != 0) throw DriverError{std::string(what) + ": " + rccl().GetErrorString(rc)}; };
     void* stream = rt_transfer_stream(g->ctx);
     if (!stream) throw DriverError{rt_last_error(g->ctx)};
@@ -820,13 +939,29 @@ double mgElapsed(rth_mg g, int a, int b) {
 
 extern "C" {
 
-// n banded frames, enqueued (asynchronous; rt_sync waits for them, both streams).
+// n banded frames, enqueued (asynchronous; rt_sync waits for them, all streams).
+// The library runs consecutive frames on alternating dispatch streams (two frames in flight), so the order of the
+// transfers decides how much of frame f+1 can run beside frame f: the gather of frame f is enqueued BEHIND the halo
+// exchange of frame f+1 (every rank enqueues halo 0, halo 1, gather 0, halo 2, gather 1, ... and the last gather at the
+// end of the call), and each wait is for a stamp, not for the present end of a stream:
+//   halo f      waits for InitialTrace + TemporalReuse of frame f (rt_stream_order)
+//   gather f-1  waits for the stamp at the end of frame f-1
+//   frame f     waits for halo f before the border rows of its first pass, and for gather f-1 before its TraceRays
+//               (which overwrites the band of Result the gather reads).
+// With the per-step timing on, a frame is waited for before the next starts, and the gather follows its own frame.
 int rth_mg_render_frames(rth_mg g, int n) {
     if (!g) return -1;
-    if (g->world > 1 && !g->comm) { g->err = "this rank was created without a communicator"; return -1; }
+    if (g->world > 1 && !g->comm && !g->hub) { g->err = "this rank was created without a communicator"; return -1; }
     try {
         std::vector<rth_xfer> plan;
-        const bool multi = g->world > 1;
+        // (a communicator of one rank has nothing to transfer, but takes the same path through the loop)
+        const bool multi = g->world > 1 || g->comm || g->hub;
+        const bool pipelined = multi && !g->timing;
+        auto gather = [&] {
+            plan.clear();
+            mgPlanGather(g, plan);
+            mgRun(g, plan);
+        };
         for (int f = 0; f < n; f++) {
             mgMark(g, 0, MK_FRAME);
             mgPhase(g, 0);
@@ -838,22 +973,35 @@ int rth_mg_render_frames(rth_mg g, int n) {
                 mgMark(g, 1, MK_HALO0);
                 mgRun(g, plan);
                 mgMark(g, 1, MK_HALO1);
+                if (pipelined) {
+                    mgCheck(g, rt_mark(g->ctx, 1, MK_HALO_DONE), "rt_mark");
+                    if (g->gatherPending) {   // the frame before: its gather travels beside this frame's reuse passes
+                        mgCheck(g, rt_wait_mark(g->ctx, 1, MK_FRAME_END), "rt_wait_mark");
+                        gather();
+                        mgCheck(g, rt_mark(g->ctx, 1, MK_GATHER_DONE), "rt_mark");
+                        g->gatherPending = false;
+                        g->gatherStamped = true;
+                    }
+                }
             }
             mgPhase(g, 1);
             mgMark(g, 0, MK_INTERIOR);
-            if (multi) mgOrder(g, 1);
+            if (pipelined) mgCheck(g, rt_wait_mark(g->ctx, 0, MK_HALO_DONE), "rt_wait_mark");
+            else if (multi) mgOrder(g, 1);
             mgPhase(g, 2);
             mgMark(g, 0, MK_POST0);
-            // (mgOrder above already made the dispatch stream wait for everything on the transfer stream, the
-            // previous frame's gather included, so TraceRays may overwrite this rank's band of Result)
+            // TraceRays overwrites this rank's band of Result: not before the last gather has read it (without the
+            // pipelining, mgOrder above already made the dispatch stream wait for everything on the transfer stream)
+            if (pipelined && g->gatherStamped) mgCheck(g, rt_wait_mark(g->ctx, 0, MK_GATHER_DONE), "rt_wait_mark");
             mgPhase(g, 3);
             mgMark(g, 0, MK_END);
-            if (multi) {
-                plan.clear();
-                mgPlanGather(g, plan);
+            if (pipelined) {
+                mgCheck(g, rt_mark(g->ctx, 0, MK_FRAME_END), "rt_mark");
+                g->gatherPending = true;
+            } else if (multi) {
                 mgOrder(g, 0);
                 mgMark(g, 1, MK_GATHER0);
-                mgRun(g, plan);
+                gather();
                 mgMark(g, 1, MK_GATHER1);
             }
             if (g->timing) {  // reading the stamps waits for the frame: timing mode gives up the overlap between frames
@@ -871,6 +1019,13 @@ int rth_mg_render_frames(rth_mg g, int n) {
                 }
                 g->timedFrames++;
             }
+        }
+        if (g->gatherPending) {   // the last frame of this call: every frame asked for is complete on rank 0 when the call's work is
+            mgCheck(g, rt_wait_mark(g->ctx, 1, MK_FRAME_END), "rt_wait_mark");
+            gather();
+            mgCheck(g, rt_mark(g->ctx, 1, MK_GATHER_DONE), "rt_mark");
+            g->gatherPending = false;
+            g->gatherStamped = true;
         }
     } catch (const DriverError& e) {
         g->err = e.msg;

@@ -238,8 +238,18 @@ typedef struct { int32_t send; int32_t peer; void* ptr; size_t bytes; } rth_xfer
  * rth_mg_render_frames hands to RCCL, in order.  rth_mg_plan returns the number of entries, or -1. */
 int rth_mg_phase(rth_mg g, int phase);
 int rth_mg_plan(rth_mg g, int which, rth_xfer* out, int cap);
-/* Enqueues n banded frames (asynchronous).  After rt_sync, rank 0's Result texture holds the whole image. */
+/* Enqueues n banded frames (asynchronous).  After rt_sync, rank 0's Result texture holds the whole image.  Collective:
+ * every rank calls it with the same n, and with the same timing switch (rth_mg_enable_timing), because the order of
+ * the transfers depends on both. */
 int rth_mg_render_frames(rth_mg g, int n);
+/* Rehearsal on ONE GPU of what rth_mg_render_frames does on several: the ranks are threads of one process, each with a
+ * context of its own on the same GPU (which RCCL refuses), and their transfers meet in a hub - same matching and
+ * ordering rules as RCCL's grouped send / receive, carried out as device copies.  Every rank's thread calls
+ * rth_mg_render_frames as usual.  rth_mg_balance and rth_mg_loopback are not available on such a rank. */
+typedef struct rth_hub_s* rth_hub;
+rth_hub rth_hub_create(int world);
+void rth_hub_destroy(rth_hub hub);   /* after the ranks made with it */
+int rth_mg_use_hub(rth_mg g, rth_hub hub);   /* `g`: made by rth_mg_create / rth_mg_create_ris without a communicator id */
 /* Per-frame breakdown, averaged over the frames rendered since timing was switched on (each frame is then waited
  * for, so frames no longer overlap): milliseconds on the dispatch stream for the whole frame, before the halo
  * exchange, for the interior rows of the first spatial pass and for everything after; on the transfer stream for the

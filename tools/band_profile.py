@@ -8,7 +8,7 @@ rank, alone on the GPU:
   frame   wall time per frame when the rank's steps are enqueued back to back for a run of frames - the way
           rth_mg_render_frames enqueues them - with the halos left as the last exchange put them (their content does
           not change what a frame costs), once with the next frame's primary rays beside the previous frame's kernels
-          (rt_set_overlap 2, what the loop uses) and once without.
+          (rt_set_overlap 2, what the loop uses) and once without; and the host time it takes to enqueue such a frame.
 
     python tools/band_profile.py [--width 3840 --height 2160 --ranks 8 --frames 24] > profiles/r03_band_times_4k.json
 """
@@ -126,6 +126,7 @@ for it in range(2 + rounds):
 
 # a rank's frames back to back, as the native loop enqueues them
 frame_ms = np.zeros((N, 2))
+enqueue_ms = np.zeros(N)
 for r, g in enumerate(ranks):
     c = ctxs[r]
     for j, mode in enumerate((2, 0)):
@@ -138,6 +139,8 @@ for r, g in enumerate(ranks):
         for _ in range(args.frames):
             for k in range(4):
                 assert host.rth_mg_phase(g, k) == 0
+        if j == 0:
+            enqueue_ms[r] = (time.perf_counter() - t0) / args.frames * 1e3
         c.sync()
         frame_ms[r, j] = (time.perf_counter() - t0) / args.frames * 1e3
     c.set_overlap(2)
@@ -151,7 +154,8 @@ out = {
                "phase_ms": {"initial_trace+temporal": phase_ms[r, 0], "spatial_pass0_interior": phase_ms[r, 1],
                             "spatial_rest+transfer": phase_ms[r, 2], "trace_rays+accumulate": phase_ms[r, 3],
                             "sum": float(phase_ms[r].sum())},
-               "frame_ms_back_to_back": {"overlap_2": frame_ms[r, 0], "overlap_0": frame_ms[r, 1]}} for r in range(N)],
+               "frame_ms_back_to_back": {"overlap_2": frame_ms[r, 0], "overlap_0": frame_ms[r, 1]},
+               "host_ms_to_enqueue_a_frame": enqueue_ms[r]} for r in range(N)],
 }
 worst = max(out["ranks"], key=lambda x: x["frame_ms_back_to_back"]["overlap_2"])
 out["max_band_frame_ms"] = worst["frame_ms_back_to_back"]["overlap_2"]
