@@ -234,13 +234,31 @@ def main():
     runner.sync()
     # Which kernel dominates the frame: the per-kernel table of 8 further untimed frames in steady state, every launch
     # bracketed by events - the kernel with the largest time per frame (average launch x launches per frame).  (Not taken
-    # from the warm-up frames: with few of them the first, untypical frames decide.)
+    # from the warm-up frames: with few of them the first, untypical frames decide.)  On one GPU these frames run with
+    # every kernel ALONE on the chip (no primary rays beside the previous frame, one frame in flight): in the timed
+    # region the library runs kernels of two frames beside one another, and the time between a launch's two events
+    # then includes the share of the chip its neighbours took - good for the frame time, useless for telling how long
+    # a kernel's own work takes.  The table of these frames is reported as `isolated_avg_ms`.
+    isolated = world == 1
+    if isolated:
+        ctx.set_overlap(0)
+        ctx.set_tuning("frames_in_flight", 1)
+        for _ in range(2):
+            runner.render_frame()
+        runner.sync()
     ctx.profile_reset()
     ctx.profile_enable(True)
     for _ in range(8):
         runner.render_frame()
     runner.sync()
     wprof = ctx.profile()
+    ctx.profile_enable(False)
+    if isolated:
+        ctx.set_overlap(1)
+        ctx.set_tuning("frames_in_flight", 1 if os.environ.get("RT_FRAMES_IN_FLIGHT") == "1" else 2)
+        for _ in range(4):   # back into the steady state of the mode that is timed
+            runner.render_frame()
+        runner.sync()
     if os.environ.get("RT_BENCH_DEBUG"):
         print({k: round(v["ms"] / max(1, v["launches"]) * 1e3, 1) for k, v in wprof.items()}, file=sys.stderr)
     dominant = max(wprof, key=lambda k: wprof[k]["ms"]) if wprof else ("ris_trace_rays" if ris else "trace_rays")
@@ -300,12 +318,16 @@ def main():
         for name, p in prof.items():
             ms = p["ms"] / max(1, p["launches"])
             entry = {"launches_per_frame": p["launches"] / steps_of[name], "avg_ms": ms}
+            if isolated and name in wprof and wprof[name]["launches"]:
+                entry["isolated_avg_ms"] = wprof[name]["ms"] / wprof[name]["launches"]
             if name in iprof:
                 c = {k: v / iprof[name]["launches"] for k, v in iprof[name].items() if k not in ("launches", "ms")}
                 b = algorithmic_bytes(name, c, band_px)
                 entry["counters_per_launch"] = {k: round(v) for k, v in c.items() if v}
                 entry["algorithmic_MB_per_launch"] = b / 1e6
                 entry["achieved_GBs"] = b / 1e9 / (ms / 1e3) if ms > 0 else None   # algorithmic bytes over time
+                if entry.get("isolated_avg_ms"):
+                    entry["isolated_achieved_GBs"] = b / 1e9 / (entry["isolated_avg_ms"] / 1e3)
             kernels[name] = entry
         # What crossed the HBM interface, per kernel, from the committed PMC passes of this same command and build.
         pmc, pmc_reason = pmc_profile(W, H, world, args.small_scene, args.scene, args.project,
@@ -333,6 +355,13 @@ def main():
             roofline = {"bound": "hbm", "kernel": dominant, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": achieved / HBM_PEAK_GBS if achieved else None, "traffic": traffic,
                         "avg_launch_ms": d["avg_ms"]}
+            if d.get("isolated_avg_ms"):
+                # the same launch with the chip to itself (see the comment at the selection of `dominant`): what the
+                # kernel's own work takes; `achieved` above is over the time the launch spent SHARING the chip
+                iso_ms = d["isolated_avg_ms"]
+                roofline["isolated"] = {"avg_launch_ms": iso_ms, "achieved": traffic / 1e9 / (iso_ms / 1e3) if traffic else None,
+                                        "frac": traffic / 1e9 / (iso_ms / 1e3) / HBM_PEAK_GBS if traffic else None,
+                                        "algorithmic_GBs": d.get("isolated_achieved_GBs")}
             if traffic is None:
                 roofline["traffic_reason"] = pmc_reason
             if d.get("algorithmic_MB_per_launch"):
@@ -370,8 +399,9 @@ def main():
                        "rays_per_frame": rays_total / args.steps},
             "roofline": roofline, "kernels": kernels,
             "traversal_kernels_Mrays_per_s": trav_rate,
-            "kernel_timing": f"HIP events on the library's stream: '{dominant}' around every launch of the timed region, "
-                             f"the other kernels in {n_breakdown} untimed frames after it",
+            "kernel_timing": f"HIP events on the stream each launch goes to: '{dominant}' around every launch of the timed region, "
+                             f"the other kernels in {n_breakdown} untimed frames after it" +
+                             ("; isolated_avg_ms: 8 untimed frames before it with one frame in flight and no overlapped primary rays" if isolated else ""),
         }
         if per_rank:
             out["per_rank_frame_ms"] = per_rank
