@@ -1422,6 +1422,20 @@ __global__ void k_build_wide(const rt_bv* BVs, int64_t nBVs, float4* wide) {
     }
     wide[n * 4 + 0] = q0; wide[n * 4 + 1] = q1; wide[n * 4 + 2] = q2; wide[n * 4 + 3] = q3;
 }
+// For the host-side validation of a scene: the two index words of every node (a quarter of the node array), and
+// whether any triangle names a vertex outside the vertex buffer (flag[0] set to 1).
+__global__ void k_extract_links(const rt_bv* BVs, int64_t nBVs, int2* links) {
+    int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= nBVs) return;
+    links[n] = make_int2(BVs[n].indexA, BVs[n].indexB);
+}
+__global__ void k_check_tri_indices(const rt_triangle* tris, int64_t nTris, int64_t nVerts, uint32_t* flag) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nTris) return;
+    const rt_triangle t = tris[i];
+    if (t.vertex0Index < 0 || t.vertex1Index < 0 || t.vertex2Index < 0 || t.vertex0Index >= nVerts || t.vertex1Index >= nVerts || t.vertex2Index >= nVerts)
+        flag[0] = 1u;
+}
 __global__ void k_obj_root_entries(const rt_bv* BVs, int64_t nBVs, const rt_scene_object* objs, int64_t nObjs, uint32_t* out) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= nObjs) return;

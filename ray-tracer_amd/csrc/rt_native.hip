@@ -17,6 +17,9 @@
 #include <mutex>
 #include <string>
 #include <algorithm>
+#include <atomic>
+#include <memory>
+#include <thread>
 #include <vector>
 
 #include "../../include/rt_native.h"
@@ -468,9 +471,10 @@ rt_texture boundTexture(rt_shader sh, int kernel, const char* name) {
 const int MAX_TREE_DEPTH = 96;  // deepest BVH (scene levels + mesh levels) the LDS stack is sized for
 
 // Depth (in nodes, root = 1) of the subtree at `root`; -1 on an index out of range, a cycle or excessive depth.
-// Leaves are checked against `nLeafTargets` (triangles or scene objects).
-int subtreeDepth(const std::vector<rt_bv>& bvs, uint32_t root, int64_t nLeafTargets, std::vector<uint8_t>& seen,
-                 std::string& why) {
+// Leaves are checked against `nLeafTargets` (triangles or scene objects).  `links` = (indexA, indexB) per node; `seen`
+// is shared by the threads that check the meshes of one scene (a node two of them reach is a shared subtree).
+struct Link { int32_t indexA, indexB; };
+int subtreeDepth(const std::vector<Link>& bvs, uint32_t root, int64_t nLeafTargets, std::atomic<uint8_t>* seen, std::string& why) {
     struct Item { uint32_t node; int depth; };
     std::vector<Item> st;
     st.push_back({root, 1});
@@ -480,10 +484,9 @@ int subtreeDepth(const std::vector<rt_bv>& bvs, uint32_t root, int64_t nLeafTarg
         st.pop_back();
         if (it.node >= bvs.size()) { why = "BVH child index out of range"; return -1; }
         if (it.depth > MAX_TREE_DEPTH) { why = "BVH deeper than the supported maximum"; return -1; }
-        if (seen[it.node] == 2) { why = "BVH node reachable twice (cycle or shared subtree)"; return -1; }
-        seen[it.node] = 2;
+        if (seen[it.node].exchange(2, std::memory_order_relaxed) == 2) { why = "BVH node reachable twice (cycle or shared subtree)"; return -1; }
         if (it.depth > maxDepth) maxDepth = it.depth;
-        const rt_bv& bv = bvs[it.node];
+        const Link& bv = bvs[it.node];
         if (bv.indexA >= 0) {
             int64_t start = bv.indexA, count = bv.indexB < 0 ? -(int64_t)bv.indexB : bv.indexB;
             if (start + count > nLeafTargets) { why = "BVH leaf range exceeds its component buffer"; return -1; }
@@ -542,33 +545,69 @@ int prepareScene(rt_shader sh, int kernel, KParams& P, bool ris = false) {
         pr.valid = false;
         pr.ris = ris;
         HIP_TRY(ctx, hipStreamSynchronize(S(ctx)));
-        std::vector<rt_bv> bvs((size_t)bBVs->count);
+        // What the host needs of the scene: the nodes' two index words (a quarter of the node array, extracted on the
+        // device) and the scene objects.  Whether the triangles' vertex indices are in range is decided on the device.
+        const size_t nNodes = (size_t)bBVs->count;
+        std::vector<Link> bvs(nNodes);
         std::vector<rt_scene_object> objs((size_t)bObjs->count);
-        std::vector<rt_triangle> tris(ris ? 0 : (size_t)bTris->count);
-        HIP_TRY(ctx, hipMemcpy(bvs.data(), bBVs->dev, bvs.size() * sizeof(rt_bv), hipMemcpyDeviceToHost));
-        HIP_TRY(ctx, hipMemcpy(objs.data(), bObjs->dev, objs.size() * sizeof(rt_scene_object), hipMemcpyDeviceToHost));
-        if (!ris) HIP_TRY(ctx, hipMemcpy(tris.data(), bTris->dev, tris.size() * sizeof(rt_triangle), hipMemcpyDeviceToHost));
         // the kernels address the 64-byte node and triangle records with 32-bit byte offsets
-        if (bvs.size() >= ((size_t)1 << 26)) return fail(ctx, RT_ERR_LIMIT, "too many BVH nodes: %zu, the limit is 2^26 - 1", bvs.size());
+        if (nNodes >= ((size_t)1 << 26)) return fail(ctx, RT_ERR_LIMIT, "too many BVH nodes: %zu, the limit is 2^26 - 1", nNodes);
         if ((uint64_t)bTris->count >= ((uint64_t)1 << 26)) return fail(ctx, RT_ERR_LIMIT, "too many triangles: %lld, the limit is 2^26 - 1", (long long)bTris->count);
-        if (sceneStart >= bvs.size()) return fail(ctx, RT_ERR_BAD_SCENE, "SceneBVHStartIndex %u is outside the BVs buffer", sceneStart);
-        for (const auto& t : tris)
-            if (t.vertex0Index < 0 || t.vertex1Index < 0 || t.vertex2Index < 0 || t.vertex0Index >= bVerts->count ||
-                t.vertex1Index >= bVerts->count || t.vertex2Index >= bVerts->count)
-                return fail(ctx, RT_ERR_BAD_SCENE, "a triangle's vertex index is outside the Vertices buffer");
-        std::vector<uint8_t> seen(bvs.size(), 0);
+        if (sceneStart >= nNodes) return fail(ctx, RT_ERR_BAD_SCENE, "SceneBVHStartIndex %u is outside the BVs buffer", sceneStart);
+        {
+            void* scratchDev = nullptr;   // links, then one flag word
+            HIP_TRY(ctx, hipMalloc(&scratchDev, nNodes * sizeof(Link) + 16));
+            uint32_t* flagDev = (uint32_t*)((char*)scratchDev + nNodes * sizeof(Link));
+            uint32_t flag = 0;
+            hipError_t e = hipMemsetAsync(flagDev, 0, 4, S(ctx));
+            hipLaunchKernelGGL(k_extract_links, dim3((unsigned)((nNodes + 255) / 256)), dim3(256), 0, S(ctx), (const rt_bv*)bBVs->dev, bBVs->count, (int2*)scratchDev);
+            if (!ris)
+                hipLaunchKernelGGL(k_check_tri_indices, dim3((unsigned)((bTris->count + 255) / 256)), dim3(256), 0, S(ctx),
+                                   (const rt_triangle*)bTris->dev, bTris->count, bVerts->count, flagDev);
+            if (e == hipSuccess) e = hipGetLastError();
+            if (e == hipSuccess) e = hipMemcpyAsync(bvs.data(), scratchDev, nNodes * sizeof(Link), hipMemcpyDeviceToHost, S(ctx));
+            if (e == hipSuccess) e = hipMemcpyAsync(&flag, flagDev, 4, hipMemcpyDeviceToHost, S(ctx));
+            if (e == hipSuccess) e = hipMemcpyAsync(objs.data(), bObjs->dev, objs.size() * sizeof(rt_scene_object), hipMemcpyDeviceToHost, S(ctx));
+            if (e == hipSuccess) e = hipStreamSynchronize(S(ctx));
+            hipError_t e2 = hipFree(scratchDev);
+            (void)e2;
+            if (e != hipSuccess) return fail(ctx, RT_ERR_NO_DEVICE, "reading the scene back for validation failed: %s", hipGetErrorString(e));
+            if (flag) return fail(ctx, RT_ERR_BAD_SCENE, "a triangle's vertex index is outside the Vertices buffer");
+        }
+        std::unique_ptr<std::atomic<uint8_t>[]> seen(new std::atomic<uint8_t>[nNodes]());
         std::string why;
-        int sceneDepth = subtreeDepth(bvs, sceneStart, bObjs->count, seen, why);
+        int sceneDepth = subtreeDepth(bvs, sceneStart, bObjs->count, seen.get(), why);
         if (sceneDepth < 0) return fail(ctx, RT_ERR_BAD_SCENE, "scene BVH (SceneBVHStartIndex %u): %s", sceneStart, why.c_str());
-        std::map<int, int> meshDepth;  // bvStartIndex -> depth
+        // the mesh BVHs, each checked once, on as many threads as the machine offers (at most 16): a 10 M-triangle
+        // scene of distinct meshes has 19 M nodes to walk
+        std::vector<int> meshRoots;
+        {
+            std::map<int, int> known;
+            for (const auto& o : objs) {
+                if (o.bvStartIndex < 0) return fail(ctx, RT_ERR_BAD_SCENE, "scene object with negative bvStartIndex");
+                if (known.emplace(o.bvStartIndex, 0).second) meshRoots.push_back(o.bvStartIndex);
+            }
+        }
+        std::vector<int> meshDepths(meshRoots.size(), 0);
+        std::vector<std::string> meshWhy(meshRoots.size());
+        {
+            unsigned nThreads = std::thread::hardware_concurrency();
+            nThreads = nThreads < 1 ? 1 : nThreads > 16 ? 16 : nThreads;
+            if (nThreads > meshRoots.size()) nThreads = (unsigned)meshRoots.size();
+            std::atomic<size_t> next(0);
+            auto work = [&] {
+                for (size_t k; (k = next.fetch_add(1)) < meshRoots.size();)
+                    meshDepths[k] = subtreeDepth(bvs, (uint32_t)meshRoots[k], bTris->count, seen.get(), meshWhy[k]);
+            };
+            std::vector<std::thread> pool;
+            for (unsigned t = 1; t < nThreads; t++) pool.emplace_back(work);
+            work();
+            for (auto& t : pool) t.join();
+        }
         int maxMeshDepth = 0;
-        for (const auto& o : objs) {
-            if (meshDepth.count(o.bvStartIndex)) continue;
-            if (o.bvStartIndex < 0) return fail(ctx, RT_ERR_BAD_SCENE, "scene object with negative bvStartIndex");
-            int d = subtreeDepth(bvs, (uint32_t)o.bvStartIndex, bTris->count, seen, why);
-            if (d < 0) return fail(ctx, RT_ERR_BAD_SCENE, "mesh BVH at %d: %s", o.bvStartIndex, why.c_str());
-            meshDepth[o.bvStartIndex] = d;
-            if (d > maxMeshDepth) maxMeshDepth = d;
+        for (size_t k = 0; k < meshRoots.size(); k++) {
+            if (meshDepths[k] < 0) return fail(ctx, RT_ERR_BAD_SCENE, "mesh BVH at %d: %s", meshRoots[k], meshWhy[k].c_str());
+            if (meshDepths[k] > maxMeshDepth) maxMeshDepth = meshDepths[k];
         }
         pr.stackDepth = sceneDepth + maxMeshDepth;   // entries stacked on the deepest path (one per internal level) + 2
         // the per-lane stack lives in LDS: 4 waves x 64 lanes x 4 bytes per entry, within the 64 KiB a workgroup may ask for
@@ -600,7 +639,7 @@ int prepareScene(rt_shader sh, int kernel, KParams& P, bool ris = false) {
         LAUNCH_TRY(ctx, "build_wide / bake_tris / obj_root_entries");
         // stack entry of the scene root, same rule as the device-side entryOf()
         {
-            const rt_bv& r = bvs[sceneStart];
+            const Link& r = bvs[sceneStart];
             if (r.indexA >= 0) {
                 if (r.indexB >= 0 && r.indexB <= ENTRY_INLINE_MAX_COUNT && r.indexA <= ENTRY_INLINE_MAX_START)
                     pr.sceneRootEntry = ENTRY_LEAF | ((uint32_t)r.indexB << 26) | (uint32_t)r.indexA;

@@ -484,3 +484,15 @@ def small_ris_config(w=64, h=64, tri_candidates=4, tests=3):
     cfg.TriCandidatesNum = tri_candidates
     cfg.SceneObjectReservoirTestsNum = cfg.TriReservoirTestsNum = cfg.CandidateReservoirTestsNum = tests
     return cfg
+
+
+def quat(axis, deg, base):
+    """base * rotation(axis, deg), as Unity composes `transform.rotation *= ...`; quaternions as x, y, z, w."""
+    a = np.asarray(axis, np.float64)
+    a = a / np.linalg.norm(a)
+    s, c = np.sin(np.radians(deg) / 2), np.cos(np.radians(deg) / 2)
+    x2, y2, z2, w2 = a[0] * s, a[1] * s, a[2] * s, c
+    x1, y1, z1, w1 = [float(v) for v in base]
+    q = np.array([w1 * x2 + x1 * w2 + y1 * z2 - z1 * y2, w1 * y2 - x1 * z2 + y1 * w2 + z1 * x2,
+                  w1 * z2 + x1 * y2 - y1 * x2 + z1 * w2, w1 * w2 - x1 * x2 - y1 * y2 - z1 * z2])
+    return [float(np.float32(v)) for v in q / np.linalg.norm(q)]

@@ -349,7 +349,7 @@ def test_native_frame_loop_rehearsed_with_threads(scene_small, world, res, frame
         for part, n in enumerate((frames, 3)):
             p = pos + np.float32(0.004 * part) * np.array([1, 0, 0.5], np.float32)
             for d in drvs:
-                d.set_camera(p, [rot[0] - 6.0 * part, rot[1] + 9.0 * part, rot[2]])
+                d.set_camera(p, h.quat((0.2, 1, 0), 7.0 * part, rot))
             run(n)
             for _ in range(n):
                 ref.render_frame()

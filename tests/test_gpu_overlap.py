@@ -34,7 +34,7 @@ def test_overlapped_frames_equal_serial_frames_1080p(gpu_ctx, scene_80k, unorm8,
         rot = [float(x) for x in cfg.cameraRotation]
 
         def move(drv, f):   # a camera that drifts and turns: hit pixels come and go, TemporalReuse reprojects
-            drv.set_camera(pos + np.float32(0.01 * f) * np.array([1, 0.2, 0.5], np.float32), [rot[0] + 0.7 * f, rot[1] - 1.1 * f, rot[2]])
+            drv.set_camera(pos + np.float32(0.01 * f) * np.array([1, 0.2, 0.5], np.float32), h.quat((0.2, 1, 0), 0.9 * f, rot))
 
         serial = rt.Driver(gpu_ctx, cfg, scene_80k)
         for f in range(frames):
@@ -109,10 +109,12 @@ def test_unsynchronised_frames_against_the_oracle(gpu_ctx, scene_small):
         # then the camera turns away: pixels that held a hit keep the reservoirs of the last frame that hit them, which
         # by then live in one or the other of the two copies the frames in flight alternate between
         for f in range(3):
-            r = [rot[0] - 25.0 * (f + 1), rot[1] + 40.0 * (f + 1), rot[2]]
+            r = h.quat((0.3, 1, 0), 35.0 * (f + 1), rot)
             drv.set_camera(pos, r); orc.set_camera(pos, r)
             drv.render_frame(); orc.render_frame()
-        assert (~np.isfinite(orc.tex["DepthBuffer"])).sum() > 0.2 * orc.tex["DepthBuffer"].size
+        # (some pixels that held a hit when the camera looked at the scene now see the sky, and some still hit)
+        sky = ~np.isfinite(orc.tex["DepthBuffer"])
+        assert sky.sum() > 0.2 * sky.size and (orc.buf["Candidates"]["totCandidates"].reshape(sky.shape)[sky] > 0).any()
         for k in BUFS:
             assert np.array_equal(h.bits(drv.buffer(k)), h.bits(orc.buf[k])), k
         for k in TEXS:
@@ -231,7 +233,7 @@ def test_uploads_between_frames_in_flight(gpu_ctx, scene_small):
         pos = np.array(cfg.cameraPosition[:], np.float32)
         rot = [float(x) for x in cfg.cameraRotation]
         for f in range(7):
-            r = [rot[0] - 12.0 * f, rot[1] + 15.0 * f, rot[2]]
+            r = h.quat((0.3, 1, 0), 14.0 * f, rot)
             for d in (plain, busy):
                 d.set_camera(pos, r)
             plain.render_frame()
