@@ -91,6 +91,12 @@ def pmc_file(W, H, small_scene, scene, project, extra=None):
     return os.path.join(ROOT, "profiles", f"r03_pmc_{tag}.json")
 
 
+def frames_in_flight_default():
+    """What new contexts start with (RT_FRAMES_IN_FLIGHT, else the library's default of 2)."""
+    e = os.environ.get("RT_FRAMES_IN_FLIGHT", "")
+    return max(1, min(4, int(e))) if e.isdigit() else 2
+
+
 def pmc_profile(W, H, world, small_scene, scene, project, extra=None):
     """(per-kernel PMC figures, None) from the committed rocprofv3 --pmc passes over this same command
     (tools/collect_profiles.sh -> tools/make_pmc_profile.py), or (None, reason) when they do not describe this run:
@@ -255,7 +261,7 @@ def main():
     ctx.profile_enable(False)
     if isolated:
         ctx.set_overlap(1)
-        ctx.set_tuning("frames_in_flight", 1 if os.environ.get("RT_FRAMES_IN_FLIGHT") == "1" else 2)
+        ctx.set_tuning("frames_in_flight", frames_in_flight_default())
         for _ in range(4):   # back into the steady state of the mode that is timed
             runner.render_frame()
         runner.sync()

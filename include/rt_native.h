@@ -92,7 +92,7 @@ int rt_flush(rt_ctx ctx);
  * the next such dispatch.
  * Two frames in flight: with a second copy of Candidates and CandidatesB as well (made at the first overlapped
  * InitialTrace; 64 + 4 bytes per pixel each, the 4 being a per-copy tag that tells a readback which copy holds a pixel's
- * newest record), consecutive frames share only TemporalFrameBuffer, Result / AccumulatedResult and the block tables,
+ * newest record; up to four copies and streams with rt_set_tuning "frames_in_flight"), consecutive frames share only TemporalFrameBuffer, Result / AccumulatedResult and the block tables,
  * so the library alternates the frames between two dispatch streams and orders only the launches that touch those.
  * What a host observes is unchanged; what changes is that "the dispatch stream" of rt_stream_order / rt_mark is the
  * stream of the frame being dispatched.  rt_stream() ends it for the context (the host's own work on that stream must
@@ -108,9 +108,10 @@ int rt_set_overlap(rt_ctx ctx, int mode);
  *                                 that walk the block table (0: one workgroup per block)
  *   "overlap_behind_candidates"  (RT_OVERLAP_START, default 1) overlapped primary rays of the ReSTIR project start only
  *                                 after the previous frame's candidate kernel (0: as early as their inputs allow)
- *   "frames_in_flight"           (RT_FRAMES_IN_FLIGHT, default 2) 2: consecutive frames alternate between two dispatch
- *                                 streams (see rt_set_overlap); 1: one dispatch stream.  Setting 2 after rt_stream()
- *                                 tells the library that the host no longer uses that stream
+ *   "frames_in_flight"           (RT_FRAMES_IN_FLIGHT, default 2) 2 to 4: consecutive frames alternate between that many
+ *                                 dispatch streams (see rt_set_overlap; 3 and 4 measured no faster than 2); 1: one
+ *                                 dispatch stream.  Setting 2 or more after rt_stream() tells the library that the
+ *                                 host no longer uses that stream
  * Unknown names fail with RT_ERR_INVALID_ARG.  No counterpart in the reference. */
 int rt_set_tuning(rt_ctx ctx, const char* name, int value);
 /* enabled = 0: every dispatch is launched by the call that makes it (nothing is held or merged); 1 (the default

@@ -62,6 +62,13 @@ struct Recs {
     uint32_t tagValue;  // the frame's number
 };
 
+// The other copies of such a buffer, for a readback (at most three: four frames in flight).
+struct OtherCopies {
+    const float4* q[3];
+    const uint32_t* tag[3];
+    int n;
+};
+
 struct Tex {
     float4* rgba;  // RGBA textures (fp32 storage)
     float* r;      // R32F textures

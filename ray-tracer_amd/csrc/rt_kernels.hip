@@ -1504,31 +1504,44 @@ __global__ void k_aos_to_recs(const float* aos, Recs rc) {
     q[2] = make_float4(r[6], r[7], r[8], r[12]);
     q[3] = make_float4(r[9], 0.0f, 0.0f, 0.0f);
 }
-// `other`, `otherTag`: the buffer's second copy and its tags, or null; a pixel whose newest record is there (the larger
-// tag) is taken from there.
-__global__ void k_recs_to_aos(Recs rc, const float4* other, const uint32_t* otherTag, float* aos, int64_t first, int64_t n) {
+// `others`: the buffer's other copies and their tags; a pixel is taken from the copy that holds its newest record (the
+// largest tag; the current copy on a tie).
+DEV int newestCopy(const Recs& rc, const OtherCopies& others, int64_t i, uint32_t* tagOut) {
+    int best = -1;
+    uint32_t t = rc.tag ? rc.tag[i] : 0u;
+    if (rc.tag)
+        for (int k = 0; k < others.n; k++) {
+            const uint32_t tk = others.tag[k][i];
+            if (tk > t) { t = tk; best = k; }
+        }
+    *tagOut = t;
+    return best;
+}
+__global__ void k_recs_to_aos(Recs rc, OtherCopies others, float* aos, int64_t first, int64_t n) {
     int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= n) return;
     float* r = aos + j * 13;
-    const bool fromOther = other && otherTag && rc.tag && otherTag[first + j] > rc.tag[first + j];
-    const float4* q = (fromOther ? other : rc.q) + (first + j) * 4;
+    uint32_t t;
+    const int from = newestCopy(rc, others, first + j, &t);
+    const float4* q = (from < 0 ? rc.q : others.q[from]) + (first + j) * 4;
     float4 a = q[0], b = q[1], c = q[2], d = q[3];
     r[0] = a.x; r[1] = a.y; r[2] = a.z; r[10] = a.w;
     r[3] = b.x; r[4] = b.y; r[5] = b.z; r[11] = b.w;
     r[6] = c.x; r[7] = c.y; r[8] = c.z; r[12] = c.w;
     r[9] = d.x;
 }
-// Makes the copy `rc` of a two-copy record buffer complete for records [first, first + n): a pixel whose newest record is
-// in the other copy gets that record, and its tag.  (Run with no frame in flight.)
-__global__ void k_recs_merge(Recs rc, const float4* other, const uint32_t* otherTag, int64_t first, int64_t n) {
+// Makes the copy `rc` of a record buffer with several copies complete for records [first, first + n): a pixel whose
+// newest record is in another copy gets that record, and its tag.  (Run with no frame in flight.)
+__global__ void k_recs_merge(Recs rc, OtherCopies others, int64_t first, int64_t n) {
     int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= n * 4) return;
     const int64_t i = first + (j >> 2);
     const int piece = (int)(j & 3);
-    const uint32_t t = otherTag[i], mine = rc.tag[i];
-    if (t <= mine) return;
-    rc.q[i * 4 + piece] = other[i * 4 + piece];
-    // (the four lanes of a record are neighbours in one wave: all have loaded the tag before this store is issued)
+    uint32_t t;
+    const int from = newestCopy(rc, others, i, &t);
+    if (from < 0) return;
+    rc.q[i * 4 + piece] = others.q[from][i * 4 + piece];
+    // (the four lanes of a record are neighbours in one wave: all have loaded the tags before this store is issued)
     if (piece == 0) rc.tag[i] = t;
 }
 // Rebuilds the workgroup -> block table with the heaviest 64x64-pixel regions first (longest-processing-time-first:

@@ -54,6 +54,14 @@ constexpr int SCRATCH_MAX_DEVICES = 64;
 static std::mutex scratchMutex;
 static rt_ctx_s* scratchOwner[SCRATCH_MAX_DEVICES] = {};
 
+constexpr int MAX_FRAMES = 4;   // frames in flight at most: dispatch streams, copies of a per-pixel object
+// The further copies of a per-pixel object the frames alternate between, the one least recently current first.
+struct Copies {
+    void* alt[MAX_FRAMES - 1] = {};
+    uint32_t* tag[MAX_FRAMES - 1] = {};   // record buffers only: the copies' tags (see Recs)
+    int n = 0;
+};
+
 struct rt_ctx_s {
     int device = 0;
     // The dispatch stream.  Every use goes through S(ctx) or SK(ctx), which first launch a held-back dispatch (see Deferred).
@@ -82,31 +90,36 @@ struct rt_ctx_s {
     // covers a row band only (a 136-row band of a 3840x2160 frame: 0.48 -> 0.37 ms per frame).  Orders that are kept:
     //  * a launch that touches one of the shared objects waits for the last launch on the OTHER frame stream that did
     //    (evShared[object][stream]); launches on one stream are in order anyway;
-    //  * the copies frame f+1 writes were current during frame f-1: at every InitialTrace that changes copies, the tails
-    //    of both frame streams are recorded for the copies being left (evSetFree[set][stream]), and the streams that will
-    //    write the set that becomes current (stream1 and the new frame stream) wait for the records made when that set
-    //    was left;
+    //  * the copies a frame writes were last current a few changes of copies ago: at every InitialTrace that changes
+    //    copies, the ends of all frame streams are recorded (evBefore), and the streams that will write the copies that
+    //    become current (stream1 and the new frame stream) wait for the record made when those copies were left;
     //  * a frame kernel that is given a record buffer the frame's InitialTrace did not change copies of (rt_buffer_s::epoch)
-    //    first waits for the other frame stream (joinOther);
+    //    first waits for the other frame stream (joinOthers);
     //  * anything else - an upload, a readback, a scene rebuild, rt_stream - goes to stream0 behind BOTH frame streams
-    //    (S(): collapse), and frame launches that follow on frameStream[1] wait for stream0 (dirty1);
+    //    (S(): collapse), and frame launches that follow on another frame stream wait for stream0 (dirty);
     //  * the table of the frame streams' kernels (BlockMap::dyn) is rewritten only with both frame streams joined.
-    // `cur`: the frame stream of the frame being dispatched; it changes at every InitialTrace whose primary rays are
-    // overlapped, when framesInFlight is 2 (rt_set_tuning "frames_in_flight", RT_FRAMES_IN_FLIGHT; 1 = one frame stream)
+    // The same with three or four frames in flight (framesInFlight streams, as many copies): what a row band of a
+    // multi-GPU run gains from (a band's launches are far from filling the chip).
+    // `cur`: the frame stream of the frame being dispatched; it moves on at every InitialTrace whose primary rays are
+    // overlapped, when framesInFlight is above 1 (rt_set_tuning "frames_in_flight", RT_FRAMES_IN_FLIGHT; 1 = one frame stream)
     // and the host has not asked for the dispatch stream itself (rt_stream: streamShared, one frame stream from then on).
-    hipStream_t frameStream[2] = {nullptr, nullptr};
+    hipStream_t frameStream[MAX_FRAMES] = {};
     int cur = 0;
-    int framesInFlight = 2;
+    int framesInFlight = 2;        // 1..MAX_FRAMES dispatch streams in use
     bool streamShared = false;
-    bool stream1Pending = false;   // frameStream[1] holds work stream0 has not been made to wait for
-    bool dirty1 = true;            // stream0 holds work frameStream[1] has not been made to wait for
-    hipEvent_t evJoin = nullptr, evTail0 = nullptr, evOther = nullptr, evTable = nullptr;
+    bool ahead[MAX_FRAMES] = {};     // [s >= 1] frameStream[s] holds work stream0 has not been made to wait for
+    bool dirty[MAX_FRAMES] = {};     // [s >= 1] stream0 holds work frameStream[s] has not been made to wait for
+    hipEvent_t evJoin[MAX_FRAMES] = {}, evOther[MAX_FRAMES] = {}, evTail0 = nullptr, evTable = nullptr;
     enum { SH_TEMPORAL = 0, SH_RESULT = 1, SH_COUNT = 2 };
-    hipEvent_t evShared[SH_COUNT][2] = {};
-    bool sharedValid[SH_COUNT][2] = {};
-    hipEvent_t evSetFree[2][2] = {};
-    bool setFreeValid[2][2] = {};
-    int curSet = 0;                // the set of copies that is current (changes with every overlapped InitialTrace)
+    hipEvent_t evShared[SH_COUNT][MAX_FRAMES] = {};
+    bool sharedValid[SH_COUNT][MAX_FRAMES] = {};
+    // evBefore[n % BEFORE_RING][s]: where frame stream s stood when the n-th change of copies was dispatched, i.e.
+    // everything dispatched before it.  An object with C copies writes, at change n, the copy that was current until
+    // change n - C + 1: its last users precede that change.
+    static constexpr int BEFORE_RING = MAX_FRAMES + 1;
+    hipEvent_t evBefore[BEFORE_RING][MAX_FRAMES] = {};
+    bool beforeValid[BEFORE_RING][MAX_FRAMES] = {};
+    uint64_t changes = 0;          // changes of copies so far
     uint64_t epoch = 2;            // number of the frame being dispatched, for the record tags (+1 whenever copies change)
     std::vector<rt_buffer> tagged; // the record buffers that have two copies
     // By choice (the default) the primary rays also wait for `evAfterCandidates`, recorded on stream0 behind every
@@ -202,12 +215,11 @@ struct rt_buffer_s {
     void* dev;
     int layout;
     uint64_t version;
-    void* alt = nullptr;  // HitInfos, Candidates, CandidatesB: the copy the next frame works on (see rt_ctx_s::stream1, frameStream)
+    Copies more;          // HitInfos, Candidates, CandidatesB: the copies the next frames work on (see rt_ctx_s::stream1, frameStream)
     // Candidates / CandidatesB only (frames write them for hit pixels alone): per copy and pixel, the number of the
     // frame that last wrote the pixel's record into that copy (see Recs).  A readback takes each pixel from the copy
     // with the larger tag.
-    uint32_t* tag = nullptr;     // of the copy `dev`
-    uint32_t* tagAlt = nullptr;  // of the copy `alt`
+    uint32_t* tag = nullptr;     // of the copy `dev` (those of the others: more.tag)
     uint64_t epoch = 0;          // rt_ctx_s::epoch when the copies last changed places
 };
 
@@ -218,7 +230,7 @@ struct rt_texture_s {
     void* dev;     // float (R32F) or float4 (others) texels
     size_t bytes;  // device bytes
     uint64_t version;  // bumped by every upload
-    void* alt = nullptr;  // DepthBuffer only: the copy the next frame's primary rays write (see rt_ctx_s::stream1)
+    Copies more;          // DepthBuffer, RayHitPointsA/B: the copies the next frames' primary rays write (see rt_ctx_s::stream1)
 };
 
 struct rt_shader_s {
@@ -282,21 +294,32 @@ void launchHeld(rt_ctx ctx);
 // The dispatch stream, for everything except the merged launches themselves: what is held back goes first.
 // SK: for the frame's own kernels and for calls that put nothing on the stream the next frame's primary rays could
 // conflict with.  S: anything else (marks the stream dirty, see rt_ctx_s::mainDirty).
-// The stream of the frame being dispatched (no held launch first).  On frameStream[1], work that went onto stream0
-// meanwhile (dirty1) is waited for first.
+// The stream of the frame being dispatched (no held launch first).  On a stream other than stream0, work that went
+// onto stream0 meanwhile (dirty) is waited for first.
 hipStream_t frameStreamNow(rt_ctx ctx) {
-    if (ctx->cur == 1) {
-        if (ctx->dirty1) {
-            if (hipEventRecord(ctx->evTail0, ctx->stream0) == hipSuccess && hipStreamWaitEvent(ctx->frameStream[1], ctx->evTail0, 0) == hipSuccess) ctx->dirty1 = false;
+    const int c = ctx->cur;
+    if (c >= 1) {
+        if (ctx->dirty[c]) {
+            if (hipEventRecord(ctx->evTail0, ctx->stream0) == hipSuccess && hipStreamWaitEvent(ctx->frameStream[c], ctx->evTail0, 0) == hipSuccess) ctx->dirty[c] = false;
         }
-        ctx->stream1Pending = true;
+        ctx->ahead[c] = true;
     }
-    return ctx->frameStream[ctx->cur];
+    return ctx->frameStream[c];
 }
-// stream0 behind everything the other frame stream holds.
+// stream0 behind everything the other frame streams hold.
 void collapse(rt_ctx ctx) {
-    if (!ctx->stream1Pending) return;
-    if (hipEventRecord(ctx->evJoin, ctx->frameStream[1]) == hipSuccess && hipStreamWaitEvent(ctx->stream0, ctx->evJoin, 0) == hipSuccess) ctx->stream1Pending = false;
+    for (int s = 1; s < MAX_FRAMES; s++) {
+        if (!ctx->ahead[s]) continue;
+        if (hipEventRecord(ctx->evJoin[s], ctx->frameStream[s]) == hipSuccess && hipStreamWaitEvent(ctx->stream0, ctx->evJoin[s], 0) == hipSuccess) ctx->ahead[s] = false;
+    }
+}
+bool anyPending(rt_ctx ctx) {
+    for (int s = 1; s < MAX_FRAMES; s++) if (ctx->ahead[s]) return true;
+    return false;
+}
+void markDirty(rt_ctx ctx) {
+    ctx->mainDirty = true;
+    for (int s = 1; s < MAX_FRAMES; s++) ctx->dirty[s] = true;
 }
 hipStream_t SK(rt_ctx ctx) {
     if (ctx->held.kind) launchHeld(ctx);
@@ -305,8 +328,7 @@ hipStream_t SK(rt_ctx ctx) {
 hipStream_t S(rt_ctx ctx) {
     if (ctx->held.kind) launchHeld(ctx);
     collapse(ctx);
-    ctx->mainDirty = true;
-    ctx->dirty1 = true;
+    markDirty(ctx);
     return ctx->stream0;
 }
 // Back to the one dispatch stream, behind everything (the start of a frame that will not run beside the one before).
@@ -315,21 +337,27 @@ void useMainStream(rt_ctx ctx) {
     collapse(ctx);
     ctx->cur = 0;
 }
-// Before / after a launch of the frame being dispatched that touches a single-copy object both frames in flight use.
+// Before / after a launch of the frame being dispatched that touches a single-copy object all frames in flight use.
 void waitShared(rt_ctx ctx, int object, hipStream_t stream) {
-    const int other = ctx->cur ^ 1;
-    if (ctx->sharedValid[object][other]) { hipError_t e = hipStreamWaitEvent(stream, ctx->evShared[object][other], 0); (void)e; }
+    for (int s = 0; s < MAX_FRAMES; s++) {
+        if (s == ctx->cur || !ctx->sharedValid[object][s]) continue;
+        hipError_t e = hipStreamWaitEvent(stream, ctx->evShared[object][s], 0);
+        (void)e;
+    }
 }
 void markShared(rt_ctx ctx, int object, hipStream_t stream) {
     if (ctx->framesInFlight < 2 || ctx->streamShared) { ctx->sharedValid[object][ctx->cur] = false; return; }
     ctx->sharedValid[object][ctx->cur] = hipEventRecord(ctx->evShared[object][ctx->cur], stream) == hipSuccess;
 }
-// The stream of the frame being dispatched waits for all the other frame stream holds.
-void joinOther(rt_ctx ctx) {
-    const int other = ctx->cur ^ 1;
-    if (other == 1 && !ctx->stream1Pending) return;   // (nothing there that stream0 is not already behind)
-    hipStream_t mine = frameStreamNow(ctx);
-    if (hipEventRecord(ctx->evOther, ctx->frameStream[other]) == hipSuccess) { hipError_t e = hipStreamWaitEvent(mine, ctx->evOther, 0); (void)e; }
+// The stream of the frame being dispatched waits for all the other frame streams hold.
+void joinOthers(rt_ctx ctx) {
+    hipStream_t mine = nullptr;
+    for (int s = 0; s < MAX_FRAMES; s++) {
+        if (s == ctx->cur || !ctx->frameStream[s]) continue;
+        if (s >= 1 && !ctx->ahead[s]) continue;   // (nothing there that stream0 is not already behind)
+        if (!mine) mine = frameStreamNow(ctx);
+        if (hipEventRecord(ctx->evOther[s], ctx->frameStream[s]) == hipSuccess) { hipError_t e = hipStreamWaitEvent(mine, ctx->evOther[s], 0); (void)e; }
+    }
 }
 void markAfterCandidates(rt_ctx ctx, hipStream_t stream) {
     if (!ctx->overlap || !ctx->behindCandidates || !ctx->evAfterCandidates) return;
@@ -358,32 +386,56 @@ Recs recsOf(rt_buffer b) {
 // Device bytes of a buffer in a given layout: reservoir records are padded from 52 to 64 bytes.
 size_t layoutBytes(rt_buffer b, int layout) { return layout == LAYOUT_RESERVOIR_RECS ? (size_t)b->count * 64 : b->bytes; }
 
+// The other copies of a record buffer and their tags, for the kernels that pick a pixel's newest record.
+OtherCopies otherCopiesOf(rt_buffer b) {
+    OtherCopies o;
+    o.n = 0;
+    for (int i = 0; i < MAX_FRAMES - 1; i++) { o.q[i] = nullptr; o.tag[i] = nullptr; }
+    if (!b->tag) return o;
+    for (int i = 0; i < b->more.n; i++) {
+        if (!b->more.alt[i] || !b->more.tag[i]) continue;
+        o.q[o.n] = (const float4*)b->more.alt[i];
+        o.tag[o.n] = b->more.tag[i];
+        o.n++;
+    }
+    return o;
+}
+void freeCopies(Copies& c) {
+    hipError_t e = hipSuccess;
+    for (int i = 0; i < MAX_FRAMES - 1; i++) {
+        if (c.alt[i]) e = hipFree(c.alt[i]);
+        if (c.tag[i]) e = hipFree(c.tag[i]);
+        c.alt[i] = nullptr; c.tag[i] = nullptr;
+    }
+    (void)e;
+    c.n = 0;
+}
 // Enqueues the conversion of a 52-byte-stride buffer's contents into the ABI layout at `dst`.
 void launchToAos(rt_buffer b, void* dst, int64_t first = 0, int64_t n = -1) {
     if (n < 0) n = b->count - first;
     if (n <= 0) return;
     const int blocks = (int)((n + 255) / 256);
-    if (b->layout == LAYOUT_RESERVOIR_RECS) hipLaunchKernelGGL(k_recs_to_aos, dim3(blocks), dim3(256), 0, S(b->ctx), recsOf(b), b->tag ? (const float4*)b->alt : nullptr, b->tagAlt, (float*)dst, first, n);
+    if (b->layout == LAYOUT_RESERVOIR_RECS) hipLaunchKernelGGL(k_recs_to_aos, dim3(blocks), dim3(256), 0, S(b->ctx), recsOf(b), otherCopiesOf(b), (float*)dst, first, n);
     else hipLaunchKernelGGL(k_planes_to_aos, dim3(blocks), dim3(256), 0, S(b->ctx), planesOf(b), (float*)dst, b->layout == LAYOUT_RESERVOIR_PLANES ? 0 : 1, first, n);
 }
 
-// A record buffer goes back to a single copy (the caller deals with `alt`).
-void dropTags(rt_buffer b) {
+// A record buffer goes back to a single copy.
+void dropCopies(rt_buffer b) {
     hipError_t e = hipSuccess;
     if (b->tag) e = hipFree(b->tag);
-    if (b->tagAlt) e = hipFree(b->tagAlt);
     (void)e;
-    b->tag = b->tagAlt = nullptr;
+    b->tag = nullptr;
+    freeCopies(b->more);
     auto& v = b->ctx->tagged;
     v.erase(std::remove(v.begin(), v.end(), b), v.end());
 }
-// Completes the current copy of records [first, first + n) of a two-copy record buffer (all of them: n < 0), on stream0
-// behind everything: afterwards that copy alone is what a single buffer would hold.
+// Completes the current copy of records [first, first + n) of a record buffer with several copies (all of them: n < 0),
+// on stream0 behind everything: afterwards that copy alone is what a single buffer would hold.
 void mergeRecords(rt_buffer b, int64_t first = 0, int64_t n = -1) {
-    if (!b->tag || !b->alt) return;
+    if (!b->tag || b->more.n == 0) return;
     if (n < 0) n = b->count - first;
     if (n <= 0) return;
-    hipLaunchKernelGGL(k_recs_merge, dim3((unsigned)((n * 4 + 255) / 256)), dim3(256), 0, S(b->ctx), recsOf(b), (const float4*)b->alt, b->tagAlt, first, n);
+    hipLaunchKernelGGL(k_recs_merge, dim3((unsigned)((n * 4 + 255) / 256)), dim3(256), 0, S(b->ctx), recsOf(b), otherCopiesOf(b), first, n);
 }
 // Before the host changes, or is given the address of, a per-pixel object the frames keep two copies of: which copy
 // holds a pixel's newest record follows from where the frames found hits, and that is what the host may now change.
@@ -404,7 +456,8 @@ int convertLayout(rt_buffer b, int target) {
     int blocks = (int)((b->count + 255) / 256);
     rt_buffer_s shadow = *b;
     shadow.dev = tmp;
-    shadow.tag = shadow.tagAlt = nullptr;
+    shadow.tag = nullptr;
+    shadow.more = Copies();
     if (target == LAYOUT_AOS) {
         launchToAos(b, tmp);
     } else if (target == LAYOUT_RESERVOIR_RECS) {
@@ -421,16 +474,8 @@ int convertLayout(rt_buffer b, int target) {
     }
     HIP_TRY(ctx, hipFree(b->dev));
     b->dev = tmp;
-    if (b->tag) {  // a tagged pair of record copies has just been merged into `tmp`: one copy again
-        dropTags(b);
-        hipError_t e3 = hipFree(b->alt);
-        (void)e3;
-        b->alt = nullptr;
-    } else if (b->alt && layoutBytes(b, target) != layoutBytes(b, b->layout)) {   // a second copy of another size is of no use
-        hipError_t e3 = hipFree(b->alt);
-        (void)e3;
-        b->alt = nullptr;
-    }
+    if (b->tag) dropCopies(b);   // the tagged copies of the records have just been merged into `tmp`: one copy again
+    else if (b->more.n && layoutBytes(b, target) != layoutBytes(b, b->layout)) freeCopies(b->more);   // copies of another size are of no use
     b->layout = target;
     return RT_OK;
 }
@@ -683,7 +728,7 @@ int needRecs(rt_shader sh, int kernel, const char* name, Recs& out, bool duringF
     if (!b) return fail(sh->ctx, RT_ERR_UNBOUND, "kernel %d: buffer '%s' is not bound", kernel, name);
     int rc = convertLayout(b, LAYOUT_RESERVOIR_RECS);
     if (rc) return rc;
-    if (duringFrame && b->epoch != sh->ctx->epoch) joinOther(sh->ctx);
+    if (duringFrame && b->epoch != sh->ctx->epoch) joinOthers(sh->ctx);
     out = recsOf(b);
     return RT_OK;
 }
@@ -884,11 +929,14 @@ void reorderBlocksMain(rt_ctx ctx, rt_ctx_s::BlockMap* m) {
     // kernels of the frame before may still be walking this table on the other frame stream: behind them, and the
     // other stream's next launches behind the new table
     hipStream_t st = SK(ctx);
-    joinOther(ctx);
+    joinOthers(ctx);
     hipLaunchKernelGGL(k_order_blocks, dim3(1), dim3(1024), 0, st, m->pendingMeasured ? m->steps : m->cost, m->bx, m->by, m->dyn, m->nDyn, m->pendingMeasured ? 1 : 0);
-    if (ctx->framesInFlight == 2 && !ctx->streamShared && hipEventRecord(ctx->evTable, st) == hipSuccess) {
-        hipError_t e = hipStreamWaitEvent(ctx->frameStream[ctx->cur ^ 1], ctx->evTable, 0);
-        (void)e;
+    if (ctx->framesInFlight >= 2 && !ctx->streamShared && hipEventRecord(ctx->evTable, st) == hipSuccess) {
+        for (int k = 0; k < ctx->framesInFlight; k++) {
+            if (k == ctx->cur) continue;
+            hipError_t e = hipStreamWaitEvent(ctx->frameStream[k], ctx->evTable, 0);
+            (void)e;
+        }
     }
     m->dynValid = true;
 }
@@ -939,64 +987,96 @@ int drainTiming(rt_ctx ctx) {
 // CandidatesB; entries may be null), the current one, orders stream1 and the frame's stream behind the last users of
 // those copies, and - `alternate` - moves on to the other frame stream.  Returns false (nothing changed) when that
 // cannot be done; the caller then launches on the one dispatch stream as usual.
-struct Flip { void** dev; void** alt; size_t bytes; };
-bool beginOverlappedPrimary(rt_ctx ctx, const Flip* flips, int n, rt_buffer const* recs, int nRecs, bool alternate) {
-    if (!ctx->stream1 || !ctx->evPrimary || !ctx->frameStream[1]) return false;
-    const bool two = alternate && ctx->framesInFlight == 2 && !ctx->streamShared;
-    for (int i = 0; i < n; i++) {
-        if (*flips[i].alt) continue;
-        if (hipMalloc(flips[i].alt, flips[i].bytes) != hipSuccess) { *flips[i].alt = nullptr; return false; }
-        // (rows a banded launch never writes must not hold garbage a readback could return)
-        if (hipMemsetAsync(*flips[i].alt, 0, flips[i].bytes, S(ctx)) != hipSuccess) return false;
+struct Flip { void** dev; Copies* more; size_t bytes; };
+// Makes sure the object has `want` copies in all (new ones are the first to be written: they go to the front of the
+// list), zeroed on stream0.  Tagged (record buffers): every copy gets tags; `tagOfCurrent` then points at the tag array
+// of the current copy, made here with tag 1 ("older than any frame, newer than the zeros of a new copy").
+bool ensureCopies(rt_ctx ctx, Copies& c, size_t bytes, int want, uint32_t** tagOfCurrent, int64_t count) {
+    want = want > MAX_FRAMES ? MAX_FRAMES : want;
+    const size_t tagBytes = (size_t)count * sizeof(uint32_t);
+    if (tagOfCurrent && !*tagOfCurrent && want >= 2) {
+        if (hipMalloc((void**)tagOfCurrent, tagBytes) != hipSuccess) { *tagOfCurrent = nullptr; return false; }
+        if (hipMemsetD32Async((hipDeviceptr_t)*tagOfCurrent, 1, (size_t)count, S(ctx)) != hipSuccess) return false;
     }
+    while (c.n + 1 < want) {
+        void* p = nullptr;
+        uint32_t* t = nullptr;
+        if (hipMalloc(&p, bytes) != hipSuccess) return false;
+        if (tagOfCurrent && hipMalloc((void**)&t, tagBytes) != hipSuccess) { hipError_t e = hipFree(p); (void)e; return false; }
+        // (rows a banded launch never writes must not hold garbage a readback could return)
+        bool ok = hipMemsetAsync(p, 0, bytes, S(ctx)) == hipSuccess;
+        if (t) ok = ok && hipMemsetAsync(t, 0, tagBytes, S(ctx)) == hipSuccess;
+        if (!ok) { hipError_t e = hipFree(p); if (t) e = hipFree(t); (void)e; return false; }
+        for (int i = c.n; i > 0; i--) { c.alt[i] = c.alt[i - 1]; c.tag[i] = c.tag[i - 1]; }
+        c.alt[0] = p; c.tag[0] = t;
+        c.n++;
+    }
+    return true;
+}
+// The copy least recently current becomes the current one.
+void rotateCopies(void** dev, uint32_t** tag, Copies& c) {
+    if (c.n == 0) return;
+    void* oldest = c.alt[0];
+    uint32_t* oldestTag = c.tag[0];
+    for (int i = 0; i + 1 < c.n; i++) { c.alt[i] = c.alt[i + 1]; c.tag[i] = c.tag[i + 1]; }
+    c.alt[c.n - 1] = *dev;
+    c.tag[c.n - 1] = tag ? *tag : nullptr;
+    *dev = oldest;
+    if (tag) *tag = oldestTag;
+}
+bool beginOverlappedPrimary(rt_ctx ctx, const Flip* flips, int n, rt_buffer const* recs, int nRecs, bool alternate) {
+    if (!ctx->stream1 || !ctx->evPrimary) return false;
+    const int K = alternate && !ctx->streamShared ? ctx->framesInFlight : 1;   // frame streams this dispatch alternates between
+    const int C = K > 2 ? K : 2;                                              // copies of what the primary rays overwrite
+    for (int k = 1; k < K; k++) if (!ctx->frameStream[k]) return false;
+    for (int i = 0; i < n; i++)
+        if (!ensureCopies(ctx, *flips[i].more, flips[i].bytes, C, nullptr, 0)) return false;
     for (int i = 0; i < nRecs; i++) {
         rt_buffer b = recs[i];
-        if (!b || (b->alt && b->tag)) continue;
-        if (!two) continue;   // one frame stream: the records keep their single copy
+        if (!b || K < 2) continue;   // one frame stream: the records keep the copies they have
         if (b->layout != LAYOUT_RESERVOIR_RECS) return false;
-        const size_t bytes = layoutBytes(b, b->layout), tagBytes = (size_t)b->count * sizeof(uint32_t);
-        if (!b->alt && hipMalloc(&b->alt, bytes) != hipSuccess) { b->alt = nullptr; return false; }
-        if (hipMalloc((void**)&b->tag, tagBytes) != hipSuccess) { b->tag = nullptr; return false; }
-        if (hipMalloc((void**)&b->tagAlt, tagBytes) != hipSuccess) { hipError_t e = hipFree(b->tag); (void)e; b->tag = b->tagAlt = nullptr; return false; }
-        // what the buffer holds now is newer than the zeros of its new copy: tag 1 against tag 0
-        hipStream_t s0 = S(ctx);
-        if (hipMemsetAsync(b->alt, 0, bytes, s0) != hipSuccess || hipMemsetD32Async((hipDeviceptr_t)b->tag, 1, b->count, s0) != hipSuccess ||
-            hipMemsetAsync(b->tagAlt, 0, tagBytes, s0) != hipSuccess) {
-            dropTags(b);
+        const bool fresh = !b->tag;
+        if (!ensureCopies(ctx, b->more, layoutBytes(b, b->layout), K, &b->tag, b->count)) {
+            if (fresh) dropCopies(b);
             return false;
         }
-        ctx->tagged.push_back(b);
+        if (fresh) ctx->tagged.push_back(b);
     }
     // everything enqueued so far uses (at most) the copies that are current now
-    const int s = ctx->curSet, o = s ^ 1;
-    if (hipEventRecord(ctx->evSetFree[s][0], ctx->stream0) != hipSuccess) return false;
-    ctx->setFreeValid[s][0] = true;
-    ctx->setFreeValid[s][1] = ctx->stream1Pending && hipEventRecord(ctx->evSetFree[s][1], ctx->frameStream[1]) == hipSuccess;
-    if (ctx->stream1Pending && !ctx->setFreeValid[s][1]) return false;
-    const int next = two ? ctx->cur ^ 1 : ctx->cur;
+    const uint64_t now = ctx->changes;
+    const int rec = (int)(now % rt_ctx_s::BEFORE_RING);
+    if (hipEventRecord(ctx->evBefore[rec][0], ctx->stream0) != hipSuccess) return false;
+    ctx->beforeValid[rec][0] = true;
+    for (int k = 1; k < MAX_FRAMES; k++) {
+        ctx->beforeValid[rec][k] = ctx->ahead[k] && hipEventRecord(ctx->evBefore[rec][k], ctx->frameStream[k]) == hipSuccess;
+        if (ctx->ahead[k] && !ctx->beforeValid[rec][k]) return false;
+    }
+    const int next = K > 1 ? (ctx->cur + 1) % K : ctx->cur;
     if (ctx->mainDirty) {  // something else went onto stream0: behind all of it, once
         collapse(ctx);
-        if (ctx->stream1Pending) return false;
+        if (anyPending(ctx)) return false;
         if (hipEventRecord(ctx->evTail0, ctx->stream0) != hipSuccess || hipStreamWaitEvent(ctx->stream1, ctx->evTail0, 0) != hipSuccess) return false;
+        markDirty(ctx);   // (and so do the other frame streams, at their next launch)
         ctx->mainDirty = false;
-        ctx->dirty1 = true;   // (and so does frameStream[1], at its next launch)
-    } else {               // the copies written from now on were current until the change of copies before this one
-        for (int k = 0; k < 2; k++) {
-            if (!ctx->setFreeValid[o][k]) continue;
-            if (hipStreamWaitEvent(ctx->stream1, ctx->evSetFree[o][k], 0) != hipSuccess) return false;
-            if (k != next && hipStreamWaitEvent(ctx->frameStream[next], ctx->evSetFree[o][k], 0) != hipSuccess) return false;
+    } else if (now + 1 >= (uint64_t)C) {
+        // the copies written from now on were current until change number now - C + 1 (an object with more copies than
+        // C, or one that changes copies less often, was left even earlier)
+        const int old = (int)((now + 1 - (uint64_t)C) % rt_ctx_s::BEFORE_RING);
+        for (int k = 0; k < MAX_FRAMES; k++) {
+            if (!ctx->beforeValid[old][k]) continue;
+            if (hipStreamWaitEvent(ctx->stream1, ctx->evBefore[old][k], 0) != hipSuccess) return false;
+            if (k != next && hipStreamWaitEvent(ctx->frameStream[next], ctx->evBefore[old][k], 0) != hipSuccess) return false;
         }
     }
     if (ctx->behindCandidates && ctx->afterCandidatesValid && hipStreamWaitEvent(ctx->stream1, ctx->evAfterCandidates, 0) != hipSuccess) return false;
-    ctx->curSet = o;
+    ctx->changes = now + 1;
     ctx->cur = next;
     ctx->epoch++;
-    for (int i = 0; i < n; i++) std::swap(*flips[i].dev, *flips[i].alt);
+    for (int i = 0; i < n; i++) rotateCopies(flips[i].dev, nullptr, *flips[i].more);
     for (int i = 0; i < nRecs; i++) {
         rt_buffer b = recs[i];
         if (!b || !b->tag) continue;
-        std::swap(b->dev, b->alt);
-        std::swap(b->tag, b->tagAlt);
+        rotateCopies(&b->dev, &b->tag, b->more);
         b->epoch = ctx->epoch;
     }
     return true;
@@ -1117,8 +1197,8 @@ int dispatchReSTIR(rt_shader sh, int kernel, int gx, int gy) {
                 rt_texture tDepth = boundTexture(sh, kernel, "DepthBuffer");
                 rt_texture tPoints = boundTexture(sh, kernel, P.FrameCount % 2 == 0 ? "RayHitPointsA" : "RayHitPointsB");
                 SK(ctx);   // (what is held goes first: it was dispatched before this)
-                const Flip flips[3] = {{&bHit->dev, &bHit->alt, layoutBytes(bHit, bHit->layout)}, {&tDepth->dev, &tDepth->alt, tDepth->bytes},
-                                       {&tPoints->dev, &tPoints->alt, tPoints->bytes}};
+                const Flip flips[3] = {{&bHit->dev, &bHit->more, layoutBytes(bHit, bHit->layout)}, {&tDepth->dev, &tDepth->more, tDepth->bytes},
+                                       {&tPoints->dev, &tPoints->more, tPoints->bytes}};
                 // the reservoirs this frame's kernels write: Candidates, and the CandidatesB that SpatialReusePass is bound to
                 rt_buffer bCandB = boundBuffer(sh, 1, "CandidatesB");
                 if (bCandB && (bCandB->layout != LAYOUT_RESERVOIR_RECS || bCandB->count < npx)) bCandB = nullptr;
@@ -1143,7 +1223,7 @@ int dispatchReSTIR(rt_shader sh, int kernel, int gx, int gy) {
                     } else if (instr) hipLaunchKernelGGL(k_primary<true>, dim3(blocks), dim3(256), ldsBytes, ls.stream, P);
                     else hipLaunchKernelGGL(k_primary<false>, dim3(blocks), dim3(256), ldsBytes, ls.stream, P);
                 }
-                if (!beside) { ctx->mainDirty = true; ctx->dirty1 = true; }   // primary rays on stream0: the next overlapped ones follow them
+                if (!beside) markDirty(ctx);   // primary rays on stream0: the next overlapped ones follow them
             }
             if (grid && grid->dyn) reorderBlocks(ctx, grid, beside);   // (the primary rays' own table: behind them, on their stream)
             if (beside && (rc = endOverlappedPrimary(ctx))) return rc;
@@ -1336,7 +1416,7 @@ int dispatchRIS(rt_shader sh, int kernel, int gx, int gy) {
             // overwrite nothing but HitInfos that those still read
             // (one frame stream: the RIS project's Candidates keep their single copy)
             useMainStream(ctx);
-            const Flip flips[1] = {{&hit->dev, &hit->alt, hit->bytes}};
+            const Flip flips[1] = {{&hit->dev, &hit->more, hit->bytes}};
             beside = mayOverlap(ctx, instr, P) && beginOverlappedPrimary(ctx, flips, 1, nullptr, 0, false);
             if (beside) P.risHit = (rt_ris_hit_info*)hit->dev;
             {
@@ -1344,7 +1424,7 @@ int dispatchRIS(rt_shader sh, int kernel, int gx, int gy) {
                 if (instr) hipLaunchKernelGGL(k_ris_primary<true>, dim3(blocks), dim3(256), ldsBytes, ls.stream, P);
                 else hipLaunchKernelGGL(k_ris_primary<false>, dim3(blocks), dim3(256), ldsBytes, ls.stream, P);
             }
-            if (!beside) { ctx->mainDirty = true; ctx->dirty1 = true; }   // primary rays on stream0: the next overlapped ones follow them
+            if (!beside) markDirty(ctx);   // primary rays on stream0: the next overlapped ones follow them
         }
         if (grid && grid->dyn) reorderBlocks(ctx, grid, beside);
         if (beside && (rc = endOverlappedPrimary(ctx))) return rc;
@@ -1498,13 +1578,15 @@ int rt_create(int device_id, rt_ctx* out) {
         static const bool lowPriority = [] { const char* e = getenv("RT_OVERLAP_PRIORITY"); return e ? atoi(e) != 0 : false; }();
         if (!lowPriority || hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) least = 0;
         static const int inFlight = [] { const char* e = getenv("RT_FRAMES_IN_FLIGHT"); return e ? atoi(e) : 2; }();
-        ctx->framesInFlight = inFlight == 1 ? 1 : 2;
+        ctx->framesInFlight = inFlight < 1 ? 1 : inFlight > MAX_FRAMES ? MAX_FRAMES : inFlight;
         ctx->frameStream[0] = ctx->stream0;
-        bool ok = hipStreamCreateWithPriority(&ctx->stream1, hipStreamNonBlocking, least) == hipSuccess &&
-                  hipStreamCreateWithFlags(&ctx->frameStream[1], hipStreamNonBlocking) == hipSuccess;
-        std::vector<hipEvent_t*> evs = {&ctx->evAfterCandidates, &ctx->evPrimary, &ctx->evJoin, &ctx->evTail0, &ctx->evOther, &ctx->evTable};
+        bool ok = hipStreamCreateWithPriority(&ctx->stream1, hipStreamNonBlocking, least) == hipSuccess;
+        for (int k = 1; k < MAX_FRAMES; k++) ok = ok && hipStreamCreateWithFlags(&ctx->frameStream[k], hipStreamNonBlocking) == hipSuccess;
+        std::vector<hipEvent_t*> evs = {&ctx->evAfterCandidates, &ctx->evPrimary, &ctx->evTail0, &ctx->evTable};
+        for (auto& ev : ctx->evJoin) evs.push_back(&ev);
+        for (auto& ev : ctx->evOther) evs.push_back(&ev);
         for (auto& per : ctx->evShared) for (auto& ev : per) evs.push_back(&ev);
-        for (auto& per : ctx->evSetFree) for (auto& ev : per) evs.push_back(&ev);
+        for (auto& per : ctx->evBefore) for (auto& ev : per) evs.push_back(&ev);
         for (hipEvent_t* ev : evs) ok = ok && hipEventCreateWithFlags(ev, hipEventDisableTiming) == hipSuccess;
         if (!ok) {
             rt_destroy(ctx);
@@ -1524,7 +1606,7 @@ void rt_destroy(rt_ctx ctx) {
     if (!ctx) return;
     hipError_t e = hipSetDevice(ctx->device);
     if (ctx->held.kind) launchHeld(ctx);
-    if (ctx->frameStream[1]) e = hipStreamSynchronize(ctx->frameStream[1]);
+    for (int k = 1; k < MAX_FRAMES; k++) if (ctx->frameStream[k]) e = hipStreamSynchronize(ctx->frameStream[k]);
     e = hipStreamSynchronize(ctx->stream0);
     {
         std::lock_guard<std::mutex> lock(scratchMutex);
@@ -1546,10 +1628,12 @@ void rt_destroy(rt_ctx ctx) {
     for (auto ev : ctx->marks) if (ev) e = hipEventDestroy(ev);
     if (ctx->transferStream) { e = hipStreamSynchronize(ctx->transferStream); e = hipStreamDestroy(ctx->transferStream); }
     if (ctx->stream1) { e = hipStreamSynchronize(ctx->stream1); e = hipStreamDestroy(ctx->stream1); }
-    if (ctx->frameStream[1]) { e = hipStreamSynchronize(ctx->frameStream[1]); e = hipStreamDestroy(ctx->frameStream[1]); }
-    for (hipEvent_t ev : {ctx->evPrimary, ctx->evAfterCandidates, ctx->evJoin, ctx->evTail0, ctx->evOther, ctx->evTable}) if (ev) e = hipEventDestroy(ev);
+    for (int k = 1; k < MAX_FRAMES; k++) if (ctx->frameStream[k]) { e = hipStreamSynchronize(ctx->frameStream[k]); e = hipStreamDestroy(ctx->frameStream[k]); }
+    for (hipEvent_t ev : {ctx->evPrimary, ctx->evAfterCandidates, ctx->evTail0, ctx->evTable}) if (ev) e = hipEventDestroy(ev);
+    for (hipEvent_t ev : ctx->evJoin) if (ev) e = hipEventDestroy(ev);
+    for (hipEvent_t ev : ctx->evOther) if (ev) e = hipEventDestroy(ev);
     for (auto& per : ctx->evShared) for (hipEvent_t ev : per) if (ev) e = hipEventDestroy(ev);
-    for (auto& per : ctx->evSetFree) for (hipEvent_t ev : per) if (ev) e = hipEventDestroy(ev);
+    for (auto& per : ctx->evBefore) for (hipEvent_t ev : per) if (ev) e = hipEventDestroy(ev);
     e = hipStreamDestroy(ctx->stream0);
     (void)e;
     delete ctx;
@@ -1559,12 +1643,13 @@ int rt_sync(rt_ctx ctx) {
     if (!ctx) return RT_ERR_INVALID_ARG;
     // (the overlapped primary rays are included: the frame streams wait for them)
     SK(ctx);
-    if (ctx->stream1Pending) {
-        HIP_TRY(ctx, hipStreamSynchronize(ctx->frameStream[1]));
-        ctx->stream1Pending = false;
+    for (int k = 1; k < MAX_FRAMES; k++) {
+        if (!ctx->ahead[k]) continue;
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->frameStream[k]));
+        ctx->ahead[k] = false;
     }
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream0));
-    ctx->dirty1 = false;   // nothing is left anywhere that a later launch would have to wait for
+    for (int k = 1; k < MAX_FRAMES; k++) ctx->dirty[k] = false;   // nothing is left anywhere that a later launch would have to wait for
     if (ctx->transferStream) HIP_TRY(ctx, hipStreamSynchronize(ctx->transferStream));
     return finish(ctx);
 }
@@ -1644,8 +1729,7 @@ int rt_set_overlap(rt_ctx ctx, int mode) {
     static const bool processOff = [] { const char* e = getenv("RT_OVERLAP"); return e && atoi(e) == 0; }();
     ctx->overlap = processOff ? 0 : mode;   // RT_OVERLAP=0 switches it off for the whole process, whatever is asked for later
     ctx->afterCandidatesValid = false;
-    ctx->mainDirty = true;   // the next overlapped primary rays follow all of stream0
-    ctx->dirty1 = true;
+    markDirty(ctx);   // the next overlapped primary rays follow all of stream0
     return finish(ctx);
 }
 int rt_set_tuning(rt_ctx ctx, const char* name, int value) {
@@ -1655,13 +1739,13 @@ int rt_set_tuning(rt_ctx ctx, const char* name, int value) {
     SK(ctx);
     if (!strcmp(name, "spatial_lds_max_offset")) ctx->spatialLdsMaxOffset = value < 0 ? 0 : value;
     else if (!strcmp(name, "primary_background_groups")) ctx->bgGroups = value < 0 ? 0 : (value + 7) / 8 * 8;
-    else if (!strcmp(name, "overlap_behind_candidates")) { ctx->behindCandidates = value != 0; ctx->afterCandidatesValid = false; ctx->mainDirty = true; ctx->dirty1 = true; }
+    else if (!strcmp(name, "overlap_behind_candidates")) { ctx->behindCandidates = value != 0; ctx->afterCandidatesValid = false; markDirty(ctx); }
     else if (!strcmp(name, "frames_in_flight")) {
-        if (value != 1 && value != 2) return fail(ctx, RT_ERR_INVALID_ARG, "frames_in_flight must be 1 or 2");
+        if (value < 1 || value > MAX_FRAMES) return fail(ctx, RT_ERR_INVALID_ARG, "frames_in_flight must be 1 to %d", MAX_FRAMES);
         useMainStream(ctx);
         ctx->framesInFlight = value;
-        if (value == 2) ctx->streamShared = false;   // (the host's word that it no longer uses the stream rt_stream gave it)
-        ctx->mainDirty = true; ctx->dirty1 = true;
+        if (value >= 2) ctx->streamShared = false;   // (the host's word that it no longer uses the stream rt_stream gave it)
+        markDirty(ctx);
     }
     else return fail(ctx, RT_ERR_INVALID_ARG, "unknown tuning parameter '%s'", name);
     return finish(ctx);
@@ -1834,7 +1918,7 @@ int rt_buffer_set_data(rt_buffer b, const void* src, size_t bytes) {
     if (bytes > b->bytes) return fail(ctx, RT_ERR_INVALID_ARG, "set_data of %zu bytes into a %zu-byte buffer", bytes, b->bytes);
     int rc = useDevice(ctx);
     if (rc) return rc;
-    if (b->alt && !b->tag) settleRecords(ctx);
+    if (b->more.n && !b->tag) settleRecords(ctx);
     if ((rc = convertLayout(b, LAYOUT_AOS))) return rc;
     // synchronous copy: the caller may reuse `src` as soon as this returns
     HIP_TRY(ctx, hipMemcpyAsync(b->dev, src, bytes, hipMemcpyHostToDevice, S(ctx)));
@@ -1911,9 +1995,9 @@ void rt_buffer_release(rt_buffer b) {
         if (pr.objRoot) e = hipFree(pr.objRoot);
         pr = rt_ctx_s::Prep();
     }
-    if (b->tag) dropTags(b);
+    if (b->tag) dropCopies(b);
+    freeCopies(b->more);
     if (b->dev) e = hipFree(b->dev);
-    if (b->alt) e = hipFree(b->alt);
     (void)e;
     delete b;
 }
@@ -1965,7 +2049,7 @@ int rt_texture_set_data(rt_texture t, const void* src, size_t bytes) {
         return finish(ctx);
     }
     if (bytes != t->bytes) return fail(ctx, RT_ERR_INVALID_ARG, "texture upload must be %zu bytes", t->bytes);
-    if (t->alt) settleRecords(ctx);
+    if (t->more.n) settleRecords(ctx);
     HIP_TRY(ctx, hipMemcpyAsync(t->dev, src, bytes, hipMemcpyHostToDevice, S(ctx)));
     HIP_TRY(ctx, hipStreamSynchronize(S(ctx)));
     t->version = ctx->versionCounter++;
@@ -2006,7 +2090,7 @@ void rt_texture_release(rt_texture t) {
         for (auto& table : sh->textures)
             for (auto it = table.begin(); it != table.end();) it = it->second == t ? table.erase(it) : std::next(it);
     if (t->dev) e = hipFree(t->dev);
-    if (t->alt) e = hipFree(t->alt);
+    freeCopies(t->more);
     (void)e;
     delete t;
 }
@@ -2023,7 +2107,7 @@ int rt_buffer_map_rows(rt_buffer b, int width, int row0, int row1, rt_segment ou
     // first made to hold what a single buffer would.
     if (ctx->overlap != 2) {
         if (b->tag) mergeRecords(b, (int64_t)first, (int64_t)n);
-        else if (b->alt) settleRecords(ctx);
+        else if (b->more.n) settleRecords(ctx);
     }
     char* base = (char*)b->dev;
     if (b->layout == LAYOUT_AOS) {
@@ -2055,7 +2139,7 @@ int rt_texture_map_rows(rt_texture t, int row0, int row1, rt_segment* out) {
     if (!t || !out) return RT_ERR_INVALID_ARG;
     if (row0 < 0 || row1 < row0 || row1 > t->h) return fail(t->ctx, RT_ERR_INVALID_ARG, "rows [%d,%d) are outside the texture", row0, row1);
     SK(t->ctx);
-    if (t->alt && t->ctx->overlap != 2) settleRecords(t->ctx);
+    if (t->more.n && t->ctx->overlap != 2) settleRecords(t->ctx);
     const size_t texel = t->format == RT_FORMAT_R32F ? 4 : 16;
     out->ptr = (char*)t->dev + (size_t)row0 * t->w * texel;
     out->bytes = (size_t)(row1 - row0) * t->w * texel;

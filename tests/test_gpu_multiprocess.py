@@ -283,11 +283,12 @@ def test_native_ris_schedule_many_ranks_in_process(scene_small, world, res):
             c.close()
 
 
-@pytest.mark.parametrize("world,res,frames,timed", [(2, (128, 96), 5, False), (4, (256, 416), 6, False), (3, (96, 160), 4, True)])
-def test_native_frame_loop_rehearsed_with_threads(scene_small, world, res, frames, timed):
+@pytest.mark.parametrize("world,res,frames,timed,in_flight", [(2, (128, 96), 5, False, 2), (4, (256, 416), 7, False, 3), (3, (96, 160), 4, True, 2),
+                                                             (2, (160, 200), 9, False, 4)])
+def test_native_frame_loop_rehearsed_with_threads(scene_small, world, res, frames, timed, in_flight):
     """rth_mg_render_frames itself with several ranks, on the one GPU: every rank is a thread with a context of its own,
     and the transfers the loop hands to RCCL go through the rehearsal hub instead (same matching and stream ordering,
-    device copies).  All frames are enqueued without a wait in between - two frames in flight per rank, the gather of a
+    device copies).  All frames are enqueued without a wait in between - two to four frames in flight per rank, the gather of a
     frame behind the next frame's halo exchange - with a camera that moves from frame to frame, and a second call
     continues the sequence.  Rank 0's gathered image and every rank's band must equal the single-GPU render."""
     import ctypes as C
@@ -298,6 +299,8 @@ def test_native_frame_loop_rehearsed_with_threads(scene_small, world, res, frame
     cfg = h.small_config(W, H)
     host = rt.host_lib()
     ctxs = [rt.RtContext(0) for _ in range(world + 1)]
+    for c in ctxs[:world]:
+        c.set_tuning("frames_in_flight", in_flight)
     drvs = [rt.Driver(c, cfg, scene_small) for c in ctxs]
     ref_ctx, ref = ctxs[world], drvs[world]
     hub = host.rth_hub_create(world)

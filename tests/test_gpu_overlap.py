@@ -22,7 +22,7 @@ def snapshot(drv):
     return {**{k: drv.buffer(k) for k in BUFS}, **{k: drv.texture(k) for k in TEXS}}
 
 
-@pytest.mark.parametrize("unorm8,in_flight", [(0, 2), (1, 2), (0, 1)])
+@pytest.mark.parametrize("unorm8,in_flight", [(0, 2), (1, 2), (0, 1), (0, 3), (1, 4)])
 def test_overlapped_frames_equal_serial_frames_1080p(gpu_ctx, scene_80k, unorm8, in_flight):
     cfg = rt.default_config()
     cfg.Unorm8RenderTargets = unorm8
@@ -93,10 +93,12 @@ def test_reads_between_the_dispatches_of_consecutive_frames(gpu_ctx, scene_small
         drv.close()
 
 
-def test_unsynchronised_frames_against_the_oracle(gpu_ctx, scene_small):
-    """Five frames enqueued without a single wait, then everything against the oracle; a moving camera makes the
+@pytest.mark.parametrize("in_flight", [2, 3, 4])
+def test_unsynchronised_frames_against_the_oracle(gpu_ctx, scene_small, in_flight):
+    """Frames enqueued without a single wait, then everything against the oracle; a moving camera makes the
     TemporalReuse of frame f read both hit-point targets, one of which frame f+1's primary rays overwrite."""
     cfg = h.small_config(200, 120)
+    gpu_ctx.set_tuning("frames_in_flight", in_flight)
     drv = rt.Driver(gpu_ctx, cfg, scene_small)
     orc = h.OracleRenderer(scene_small.arrays(), cfg)
     try:
@@ -120,6 +122,7 @@ def test_unsynchronised_frames_against_the_oracle(gpu_ctx, scene_small):
         for k in TEXS:
             assert np.array_equal(h.bits(drv.texture(k)), h.bits(orc.tex[k])), k
     finally:
+        gpu_ctx.set_tuning("frames_in_flight", 2)
         drv.close()
 
 
@@ -224,10 +227,12 @@ def test_two_drivers_taking_turns_on_one_context(gpu_ctx, scene_small):
             d.close()
 
 
-def test_uploads_between_frames_in_flight(gpu_ctx, scene_small):
+@pytest.mark.parametrize("in_flight", [2, 3])
+def test_uploads_between_frames_in_flight(gpu_ctx, scene_small, in_flight):
     """A host that reads a per-pixel object back and uploads it again between frames changes nothing: the reservoirs come
     back merged from their two copies, the upload makes one copy of them, and the frames go on alternating."""
     cfg = h.small_config(152, 104)
+    gpu_ctx.set_tuning("frames_in_flight", in_flight)
     plain, busy = rt.Driver(gpu_ctx, cfg, scene_small), rt.Driver(gpu_ctx, cfg, scene_small)
     try:
         pos = np.array(cfg.cameraPosition[:], np.float32)
@@ -251,6 +256,7 @@ def test_uploads_between_frames_in_flight(gpu_ctx, scene_small):
         for k in want:
             assert np.array_equal(h.bits(want[k]), h.bits(got[k])), k
     finally:
+        gpu_ctx.set_tuning("frames_in_flight", 2)
         plain.close()
         busy.close()
 

@@ -1,5 +1,5 @@
 #!/bin/bash
-# Copies what tools/collect_profiles.sh left under gpurun_out/ into profiles/ (tracked), named for this round.
+# Copies what tools/collect_profiles.sh left under gpurun_out/ into profiles/ (tracked), under the prefix R.
 set -e
 R=r03
 cp "$(ls -t gpurun_out/ktrace/*/*_kernel_stats.csv | head -1)" profiles/${R}_kernel_stats.csv
