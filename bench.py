@@ -235,8 +235,17 @@ def main():
 
     ctx = runner.ctx
     ctx.enable_stats(1)
-    for _ in range(args.warmup):   # untimed: tables ranked, temporal history built, clocks up
-        runner.render_frame()
+
+    def render(n):
+        # the native multi-GPU loop takes the whole run of frames in one call: it keeps the gather of a frame behind the
+        # next frame's halo exchange, and completes the last frame's gather at the end of the call
+        if hasattr(runner, "render_frames"):
+            runner.render_frames(n)
+        else:
+            for _ in range(n):
+                runner.render_frame()
+
+    render(args.warmup)   # untimed: tables ranked, temporal history built, clocks up
     runner.sync()
     # Which kernel dominates the frame: the per-kernel table of 8 further untimed frames in steady state, every launch
     # bracketed by events - the kernel with the largest time per frame (average launch x launches per frame).  (Not taken
@@ -249,21 +258,18 @@ def main():
     if isolated:
         ctx.set_overlap(0)
         ctx.set_tuning("frames_in_flight", 1)
-        for _ in range(2):
-            runner.render_frame()
+        render(2)
         runner.sync()
     ctx.profile_reset()
     ctx.profile_enable(True)
-    for _ in range(8):
-        runner.render_frame()
+    render(8)
     runner.sync()
     wprof = ctx.profile()
     ctx.profile_enable(False)
     if isolated:
         ctx.set_overlap(1)
         ctx.set_tuning("frames_in_flight", frames_in_flight_default())
-        for _ in range(4):   # back into the steady state of the mode that is timed
-            runner.render_frame()
+        render(4)   # back into the steady state of the mode that is timed
         runner.sync()
     if os.environ.get("RT_BENCH_DEBUG"):
         print({k: round(v["ms"] / max(1, v["launches"]) * 1e3, 1) for k, v in wprof.items()}, file=sys.stderr)
@@ -274,8 +280,7 @@ def main():
     ctx.profile_enable(True, only=dominant)
     runner.barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        runner.render_frame()
+    render(args.steps)
     runner.sync()
     runner.barrier()
     dt = time.perf_counter() - t0
@@ -288,8 +293,7 @@ def main():
     ctx.profile_reset()
     ctx.profile_enable(True)
     n_breakdown = max(1, min(args.steps, 16))
-    for _ in range(n_breakdown):
-        runner.render_frame()
+    render(n_breakdown)
     runner.sync()
     ctx.profile_enable(False)
     prof = ctx.profile()
@@ -301,8 +305,7 @@ def main():
     ctx.profile_reset()
     ctx.enable_stats(2)
     n_instr = 4
-    for _ in range(n_instr):
-        runner.render_frame()
+    render(n_instr)
     runner.sync()
     iprof = ctx.profile()
     ctx.enable_stats(0)

@@ -365,3 +365,4 @@ def test_native_frame_loop_rehearsed_with_threads(scene_small, world, res, frame
             d.close()
         for c in ctxs:
             c.close()
+
