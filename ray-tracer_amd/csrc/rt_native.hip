@@ -963,6 +963,16 @@ struct LaunchScope {
     }
     ~LaunchScope() {
         checkLaunch(ctx, IK_NAMES[ik]);
+        // debugging aid (RT_SYNC_LAUNCH=1): wait for every launch, so that a fault is reported with the kernel that made it
+        static const bool syncLaunch = [] { const char* e = getenv("RT_SYNC_LAUNCH"); return e && atoi(e) != 0; }();
+        if (syncLaunch) {
+            const hipError_t e = hipStreamSynchronize(stream);
+            if (e != hipSuccess && !ctx->stickyRc) {
+                ctx->stickyRc = RT_ERR_LAUNCH;
+                ctx->stickyMsg = std::string("kernel '") + IK_NAMES[ik] + "' failed on the device: " + hipGetErrorString(e);
+                fprintf(stderr, "rtnative: %s\n", ctx->stickyMsg.c_str());
+            }
+        }
         if (!start || !stop) return;
         hipError_t e = hipEventRecord(stop, stream);
         (void)e;

@@ -542,6 +542,10 @@ struct rth_hub_s {
     std::condition_variable cv;
     std::vector<std::deque<std::shared_ptr<SendRec>>> queue;   // [src * world + dst]
     bool broken = false;   // a rank gave up: nobody waits any longer
+    // The events of finished transfers.  They are destroyed with the hub, not when the sender has enqueued its wait:
+    // a wait on them may still be pending on a stream of another rank's thread, and nothing is gained by finding out
+    // what the runtime makes of an event destroyed under it.
+    std::vector<void*> spent;
 };
 
 struct rth_mg_s {
@@ -679,7 +683,11 @@ rth_hub rth_hub_create(int world) {
     hub->queue.resize((size_t)world * world);
     return hub;
 }
-void rth_hub_destroy(rth_hub hub) { delete hub; }
+void rth_hub_destroy(rth_hub hub) {
+    if (!hub) return;
+    for (void* ev : hub->spent) hipRt().EventDestroy(ev);   // (the ranks made with the hub are gone: their streams were waited for)
+    delete hub;
+}
 int rth_mg_use_hub(rth_mg g, rth_hub hub) {
     if (!g || !hub) return -1;
     if (g->comm) { g->err = "this rank already has a communicator"; return -1; }
@@ -908,8 +916,9 @@ void hubRun(rth_mg g, const std::vector<rth_xfer>& plan) {
             if (hub->broken) throw DriverError{"another rank of the rehearsal gave up"};
         }
         check(hip.StreamWaitEvent(stream, rec->copied, 0), "hipStreamWaitEvent");
-        hip.EventDestroy(rec->ready);    // (released by the runtime once the work that refers to them is done)
-        hip.EventDestroy(rec->copied);
+        std::lock_guard<std::mutex> l(hub->mu);
+        hub->spent.push_back(rec->ready);
+        hub->spent.push_back(rec->copied);
     }
 }
 void mgRun(rth_mg g, const std::vector<rth_xfer>& plan) {
