@@ -141,6 +141,52 @@ def test_bad_scene_is_rejected(gpu_ctx, scene_small):
         drv.close()
 
 
+def test_bad_triangles_and_shared_subtrees_are_rejected(gpu_ctx, scene_small):
+    """The triangle indices are checked on the device and the mesh BVHs on several host threads: a vertex index beyond
+    the vertex buffer, and a node that two parents name, are both refused."""
+    a = scene_small.arrays()
+    cfg = h.small_config(32, 32)
+    drv = rt.Driver(gpu_ctx, cfg, scene_small)
+    try:
+        tris = a["Triangles"].copy()
+        tris["v"][len(tris) // 2][1] = len(a["Vertices"]) + 3
+        gpu_ctx.set_buffer_data(drv.buffer_handle("Triangles"), tris)
+        with pytest.raises(rt.NativeError, match="vertex index"):
+            drv.render_frame()
+        gpu_ctx.set_buffer_data(drv.buffer_handle("Triangles"), a["Triangles"])
+        bvs = a["BVs"].copy()
+        start = int(a["SceneObjects"]["bvStartIndex"].max())       # a mesh root: an internal node
+        assert bvs["indexA"][start] < 0
+        bvs["indexB"][start] = bvs["indexA"][start]                # both children the same node
+        gpu_ctx.set_buffer_data(drv.buffer_handle("BVs"), bvs)
+        with pytest.raises(rt.NativeError, match="reachable twice"):
+            drv.render_frame()
+        gpu_ctx.set_buffer_data(drv.buffer_handle("BVs"), a["BVs"])
+        drv.render_frame()
+        gpu_ctx.sync()
+    finally:
+        drv.close()
+
+
+def test_stamps_and_row_reports_check_their_arguments(gpu_ctx):
+    lib = gpu_ctx.lib
+    assert lib.rt_wait_mark(gpu_ctx.h, 0, 63) < 0 and b"never recorded" in lib.rt_last_error(gpu_ctx.h)
+    assert lib.rt_wait_mark(gpu_ctx.h, 2, 0) < 0 and lib.rt_wait_mark(gpu_ctx.h, 0, 64) < 0
+    gpu_ctx.check(lib.rt_mark(gpu_ctx.h, 0, 40), "rt_mark")
+    gpu_ctx.check(lib.rt_wait_mark(gpu_ctx.h, 0, 40), "rt_wait_mark")     # same stream: a no-op that must be accepted
+    gpu_ctx.check(lib.rt_wait_mark(gpu_ctx.h, 1, 40), "rt_wait_mark")     # creates the transfer stream
+    buf = gpu_ctx.create_buffer(64, 52)
+    try:
+        assert lib.rt_buffer_rows_written(buf, 8, 0, 9) < 0               # 9 rows of 8 do not fit 64 records
+        assert lib.rt_buffer_rows_written(buf, 8, 5, 4) < 0
+        gpu_ctx.check(lib.rt_buffer_rows_written(buf, 8, 0, 8), "rt_buffer_rows_written")   # a buffer with one copy: nothing to do
+    finally:
+        lib.rt_buffer_release(buf)
+    with pytest.raises(rt.NativeError):
+        gpu_ctx.set_tuning("frames_in_flight", 5)
+    gpu_ctx.sync()
+
+
 def test_buffer_roundtrip_keeps_abi_layout(gpu_ctx, scene_small):
     """Reservoir buffers live as planes inside the library; set_data/get_data always speak the 52-byte records."""
     cfg = h.small_config(16, 16)
