@@ -112,6 +112,11 @@ int rt_set_overlap(rt_ctx ctx, int mode);
  *                                 dispatch streams (see rt_set_overlap; 3 and 4 measured no faster than 2); 1: one
  *                                 dispatch stream.  Setting 2 or more after rt_stream() tells the library that the
  *                                 host no longer uses that stream
+ *   "debug_stream_delay_us"      (default 0) test aid: before about every second launch its stream is held up for a
+ *                                 pseudo-random time of up to this many microseconds (at most 2000), so that a missing
+ *                                 order between launches of frames in flight shows as a wrong image
+ *   "debug_stream_delay_mask"    (default 255) which streams that applies to: bit k = dispatch stream k, bit 7 = the
+ *                                 stream of the overlapped primary rays
  * Unknown names fail with RT_ERR_INVALID_ARG.  No counterpart in the reference. */
 int rt_set_tuning(rt_ctx ctx, const char* name, int value);
 /* enabled = 0: every dispatch is launched by the call that makes it (nothing is held or merged); 1 (the default

@@ -1598,6 +1598,13 @@ __global__ __launch_bounds__(1024) void k_order_blocks(const uint32_t* costW, in
     }
 }
 
+// Test aid: occupies a stream for about `ticks` ticks of the 100 MHz wall clock (one wave; gives up after 4 ms whatever
+// is asked for, so it always ends).
+__global__ void k_delay(unsigned long long ticks) {
+    if (ticks > 400000ull) ticks = 400000ull;
+    const unsigned long long t0 = wall_clock64();
+    while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(32);
+}
 __global__ void k_rgba8_to_f32(const uint8_t* src, float4* dst, int64_t n) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;

@@ -135,6 +135,14 @@ struct rt_ctx_s {
     // ordinary launch) walk the block table through bgCounter (8 words, one per XCD, cleared on stream1 before each launch).
     int bgGroups = 0;
     uint32_t* bgCounter = nullptr;
+    // Test aid (rt_set_tuning "debug_stream_delay_us"): before about every second launch the stream it goes to is held up
+    // for a pseudo-random time up to this many microseconds, which moves the kernels of the frames in flight against
+    // one another in ways a quiet machine never shows: a missing wait between two launches then changes the image.
+    // "debug_stream_delay_mask": which streams are held up - bit k: dispatch stream k, bit 7: the primary rays' stream
+    // (default all).  Holding up ONE stream makes the others run ahead of it wherever nothing orders them.
+    int debugDelayUs = 0;
+    int debugDelayMask = 0xff;
+    uint32_t debugDelayState = 12345u;
     int spatialLdsMaxOffset = 0;  // largest MaxOffset for which SpatialReusePass stages its neighbourhood in LDS (0 = never)
     bool bigLdsAllowed = false;   // k_spatial_lds may ask for more than 64 KiB of dynamic LDS on this device
     hipStream_t transferStream = nullptr;  // created by rt_transfer_stream
@@ -948,6 +956,13 @@ struct LaunchScope {
     hipEvent_t start = nullptr, stop = nullptr;
     hipStream_t stream;
     LaunchScope(rt_ctx c, int k, KParams* P, hipStream_t on = nullptr) : ctx(c), ik(k), stream(on ? on : SK(c)) {
+        if (ctx->debugDelayUs > 0 && !ctx->noAlloc) {
+            ctx->debugDelayState = ctx->debugDelayState * 1664525u + 1013904223u;
+            const uint32_t r = ctx->debugDelayState >> 8;
+            int bit = stream == ctx->stream1 ? 7 : 0;
+            for (int s = 1; s < MAX_FRAMES; s++) if (stream == ctx->frameStream[s]) bit = s;
+            if ((r & 1u) && ((ctx->debugDelayMask >> bit) & 1)) hipLaunchKernelGGL(k_delay, dim3(1), dim3(64), 0, stream, (unsigned long long)((r >> 1) % (uint32_t)ctx->debugDelayUs) * 100ull);
+        }
         if (P) { P->stats = ctx->statsLevel > 0 ? ctx->statsDev + (size_t)k * STAT_SHARDS * 8 : nullptr; P->statsLevel = ctx->statsLevel; }
         ctx->launches[k]++;
         if (!ctx->timing || ctx->noAlloc || (ctx->timingOnly >= 0 && ctx->timingOnly != k)) return;
@@ -1591,7 +1606,9 @@ int rt_create(int device_id, rt_ctx* out) {
         ctx->framesInFlight = inFlight < 1 ? 1 : inFlight > MAX_FRAMES ? MAX_FRAMES : inFlight;
         ctx->frameStream[0] = ctx->stream0;
         bool ok = hipStreamCreateWithPriority(&ctx->stream1, hipStreamNonBlocking, least) == hipSuccess;
-        for (int k = 1; k < MAX_FRAMES; k++) ok = ok && hipStreamCreateWithFlags(&ctx->frameStream[k], hipStreamNonBlocking) == hipSuccess;
+        // (the third and fourth dispatch stream are made when they are asked for: a process has few hardware queues -
+        // four by default - and streams that share one run one after the other)
+        for (int k = 1; k < ctx->framesInFlight; k++) ok = ok && hipStreamCreateWithFlags(&ctx->frameStream[k], hipStreamNonBlocking) == hipSuccess;
         std::vector<hipEvent_t*> evs = {&ctx->evAfterCandidates, &ctx->evPrimary, &ctx->evTail0, &ctx->evTable};
         for (auto& ev : ctx->evJoin) evs.push_back(&ev);
         for (auto& ev : ctx->evOther) evs.push_back(&ev);
@@ -1750,9 +1767,13 @@ int rt_set_tuning(rt_ctx ctx, const char* name, int value) {
     if (!strcmp(name, "spatial_lds_max_offset")) ctx->spatialLdsMaxOffset = value < 0 ? 0 : value;
     else if (!strcmp(name, "primary_background_groups")) ctx->bgGroups = value < 0 ? 0 : (value + 7) / 8 * 8;
     else if (!strcmp(name, "overlap_behind_candidates")) { ctx->behindCandidates = value != 0; ctx->afterCandidatesValid = false; markDirty(ctx); }
+    else if (!strcmp(name, "debug_stream_delay_us")) ctx->debugDelayUs = value < 0 ? 0 : value > 2000 ? 2000 : value;
+    else if (!strcmp(name, "debug_stream_delay_mask")) ctx->debugDelayMask = value & 0xff;
     else if (!strcmp(name, "frames_in_flight")) {
         if (value < 1 || value > MAX_FRAMES) return fail(ctx, RT_ERR_INVALID_ARG, "frames_in_flight must be 1 to %d", MAX_FRAMES);
         useMainStream(ctx);
+        for (int k = 1; k < value; k++)
+            if (!ctx->frameStream[k]) HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->frameStream[k], hipStreamNonBlocking));
         ctx->framesInFlight = value;
         if (value >= 2) ctx->streamShared = false;   // (the host's word that it no longer uses the stream rt_stream gave it)
         markDirty(ctx);

@@ -283,9 +283,10 @@ def test_native_ris_schedule_many_ranks_in_process(scene_small, world, res):
             c.close()
 
 
-@pytest.mark.parametrize("world,res,frames,timed,in_flight", [(2, (128, 96), 5, False, 2), (4, (256, 416), 7, False, 3), (3, (96, 160), 4, True, 2),
-                                                             (2, (160, 200), 9, False, 4)])
-def test_native_frame_loop_rehearsed_with_threads(scene_small, world, res, frames, timed, in_flight):
+@pytest.mark.parametrize("world,res,frames,timed,in_flight,delay_us", [(2, (128, 96), 5, False, 2, 0), (4, (256, 416), 7, False, 3, 0),
+                                                                      (3, (96, 160), 4, True, 2, 0), (2, (160, 200), 9, False, 4, 0),
+                                                                      (3, (128, 264), 8, False, 2, 150)])
+def test_native_frame_loop_rehearsed_with_threads(scene_small, world, res, frames, timed, in_flight, delay_us):
     """rth_mg_render_frames itself with several ranks, on the one GPU: every rank is a thread with a context of its own,
     and the transfers the loop hands to RCCL go through the rehearsal hub instead (same matching and stream ordering,
     device copies).  All frames are enqueued without a wait in between - two to four frames in flight per rank, the gather of a
@@ -301,6 +302,7 @@ def test_native_frame_loop_rehearsed_with_threads(scene_small, world, res, frame
     ctxs = [rt.RtContext(0) for _ in range(world + 1)]
     for c in ctxs[:world]:
         c.set_tuning("frames_in_flight", in_flight)
+        c.set_tuning("debug_stream_delay_us", delay_us)   # (test aid: the library's streams held up at random, see test_gpu_overlap)
     drvs = [rt.Driver(c, cfg, scene_small) for c in ctxs]
     ref_ctx, ref = ctxs[world], drvs[world]
     hub = host.rth_hub_create(world)

@@ -93,12 +93,20 @@ def test_reads_between_the_dispatches_of_consecutive_frames(gpu_ctx, scene_small
         drv.close()
 
 
-@pytest.mark.parametrize("in_flight", [2, 3, 4])
-def test_unsynchronised_frames_against_the_oracle(gpu_ctx, scene_small, in_flight):
+@pytest.mark.parametrize("in_flight,delay_us,mask", [(2, 0, 255), (3, 0, 255), (4, 0, 255), (1, 120, 255), (2, 60, 255), (2, 200, 255), (3, 150, 255),
+                                                     (4, 90, 255), (2, 300, 1), (2, 300, 2), (2, 300, 128), (3, 300, 4), (3, 300, 3), (2, 300, 129)])
+def test_unsynchronised_frames_against_the_oracle(gpu_ctx, scene_small, in_flight, delay_us, mask):
     """Frames enqueued without a single wait, then everything against the oracle; a moving camera makes the
-    TemporalReuse of frame f read both hit-point targets, one of which frame f+1's primary rays overwrite."""
+    TemporalReuse of frame f read both hit-point targets, one of which frame f+1's primary rays overwrite.
+    With delay_us the library holds its streams up for pseudo-random times before about every second launch (test aid
+    "debug_stream_delay_us"), far longer than these small kernels run: the kernels of the frames in flight then meet in
+    orders a quiet machine never produces, and only the waits the library enqueues keep the result right.  With a mask
+    only some streams are held up (one dispatch stream, the primary rays' stream): the others then run ahead of them
+    wherever nothing orders them."""
     cfg = h.small_config(200, 120)
     gpu_ctx.set_tuning("frames_in_flight", in_flight)
+    gpu_ctx.set_tuning("debug_stream_delay_us", delay_us)
+    gpu_ctx.set_tuning("debug_stream_delay_mask", mask)
     drv = rt.Driver(gpu_ctx, cfg, scene_small)
     orc = h.OracleRenderer(scene_small.arrays(), cfg)
     try:
@@ -123,11 +131,14 @@ def test_unsynchronised_frames_against_the_oracle(gpu_ctx, scene_small, in_fligh
             assert np.array_equal(h.bits(drv.texture(k)), h.bits(orc.tex[k])), k
     finally:
         gpu_ctx.set_tuning("frames_in_flight", 2)
+        gpu_ctx.set_tuning("debug_stream_delay_us", 0)
         drv.close()
 
 
-def test_ris_frames_overlap_and_match(gpu_ctx, scene_small):
+@pytest.mark.parametrize("delay_us", [0, 100])
+def test_ris_frames_overlap_and_match(gpu_ctx, scene_small, delay_us):
     cfg = h.small_ris_config(120, 88)
+    gpu_ctx.set_tuning("debug_stream_delay_us", delay_us)
     drv = rt.RisDriver(gpu_ctx, cfg, scene_small)
     orc = h.RisOracleRenderer(scene_small.arrays(), cfg)
     try:
@@ -145,6 +156,7 @@ def test_ris_frames_overlap_and_match(gpu_ctx, scene_small):
         for k in ("Result", "AccumulatedResult", "DebugOverlay", "RayHitPoints"):
             assert np.array_equal(h.bits(drv.texture(k)), h.bits(orc.tex[k])), k
     finally:
+        gpu_ctx.set_tuning("debug_stream_delay_us", 0)
         drv.close()
 
 
@@ -202,7 +214,8 @@ def test_speed_only_choices_leave_every_bit_alone(gpu_ctx, scene_small, name, va
             gpu_ctx.set_tuning(n, v)
 
 
-def test_two_drivers_taking_turns_on_one_context(gpu_ctx, scene_small):
+@pytest.mark.parametrize("delay_us", [0, 120])
+def test_two_drivers_taking_turns_on_one_context(gpu_ctx, scene_small, delay_us):
     """Frames of two frame loops enqueued alternately, and two in a row: each loop's frames equal the frames it renders
     on its own (the copies and streams the frames alternate between belong to the context, the buffers to the loops)."""
     cfg_a, cfg_b = h.small_config(136, 96), h.small_config(96, 136)
@@ -216,6 +229,7 @@ def test_two_drivers_taking_turns_on_one_context(gpu_ctx, scene_small):
         alone.close()
     drv = {"a": rt.Driver(gpu_ctx, cfg_a, scene_small), "b": rt.Driver(gpu_ctx, cfg_b, scene_small)}
     try:
+        gpu_ctx.set_tuning("debug_stream_delay_us", delay_us)
         for name in order:
             drv[name].render_frame()
         for name in "ab":
@@ -223,6 +237,7 @@ def test_two_drivers_taking_turns_on_one_context(gpu_ctx, scene_small):
             for k in got:
                 assert np.array_equal(h.bits(want[name][k]), h.bits(got[k])), f"{name}: {k}"
     finally:
+        gpu_ctx.set_tuning("debug_stream_delay_us", 0)
         for d in drv.values():
             d.close()
 
