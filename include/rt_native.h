@@ -119,6 +119,25 @@ int rt_set_overlap(rt_ctx ctx, int mode);
  *                                 stream of the overlapped primary rays
  * Unknown names fail with RT_ERR_INVALID_ARG.  No counterpart in the reference. */
 int rt_set_tuning(rt_ctx ctx, const char* name, int value);
+/* Test aid: a log of what the library puts on which of its streams.  rt_debug_trace(ctx, 1) starts a new log, (ctx, 0)
+ * stops it; rt_debug_trace_dump writes it as text (at most `capacity` bytes with the terminating 0) and returns the
+ * bytes the whole text needs.  One line per operation, in the order the host enqueued them:
+ *   L <stream> <kernel> <object>:<r|w>[~][:<row0>-<row1>] ...   a launch and the per-pixel objects (device addresses of
+ *                                               the copies) it reads / writes, with the image rows when it works on a
+ *                                               band; ~ marks counts another kernel may read while they are rewritten
+ *   R <stream> <event>    an event recorded          W <stream> <event>    a stream made to wait for an event
+ *   H 0                   a host operation on dispatch stream 0 (a copy, a conversion, a scene rebuild: may touch anything)
+ *   Y 0                   rt_sync: the host has waited for every stream
+ * Streams: 0..3 the dispatch streams, 4 the overlapped primary rays' stream, 5 the transfer stream.  From the log alone
+ * it can be decided whether every two launches that touch the same memory, one of them writing, are ordered by the
+ * streams and events - whatever the timing (tests/harness.py does).  No counterpart in the reference. */
+int rt_debug_trace(rt_ctx ctx, int on);
+int64_t rt_debug_trace_dump(rt_ctx ctx, void* out, int64_t capacity);
+/* For a host that moves rows itself (the multi-GPU loop's halo exchange and gather): adds to the log that work it has
+ * just enqueued on `stream` (0 = the dispatch stream of the frame being dispatched, 1 = the transfer stream) reads
+ * (write = 0) or writes rows [row0, row1) of the current copy of a buffer and / or a texture.  Does nothing when no
+ * log is being kept. */
+int rt_debug_note_rows(rt_ctx ctx, int stream, rt_buffer buf, rt_texture tex, int row0, int row1, int write);
 /* enabled = 0: every dispatch is launched by the call that makes it (nothing is held or merged); 1 (the default
  * unless RT_FUSE=0 is in the environment): consecutive dispatches that can run as one launch do.  Results are
  * bit-identical either way.  No counterpart in the reference. */

@@ -76,6 +76,9 @@ internal static class RtNative
     [DllImport(Lib)] public static extern int rt_stream_order(IntPtr ctx, int first);
     [DllImport(Lib)] public static extern int rt_mark(IntPtr ctx, int stream, int slot);
     [DllImport(Lib)] public static extern int rt_wait_mark(IntPtr ctx, int stream, int slot);
+    [DllImport(Lib)] public static extern int rt_debug_trace(IntPtr ctx, int on);
+    [DllImport(Lib)] public static extern int rt_debug_note_rows(IntPtr ctx, int stream, IntPtr buffer, IntPtr texture, int row0, int row1, int write);
+    [DllImport(Lib)] public static extern long rt_debug_trace_dump(IntPtr ctx, IntPtr text, long capacity);
     [DllImport(Lib)] public static extern int rt_mark_elapsed(IntPtr ctx, int slotA, int slotB, out double milliseconds);
 
     // measurement

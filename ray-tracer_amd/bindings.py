@@ -65,7 +65,9 @@ def native_lib():
             "rt_create": (ci, [ci, C.POINTER(vp)]), "rt_destroy": (None, [vp]), "rt_sync": (ci, [vp]),
             "rt_last_error": (cs, [vp]), "rt_stream": (vp, [vp]), "rt_transfer_stream": (vp, [vp]),
             "rt_flush": (ci, [vp]), "rt_set_fusion": (ci, [vp, ci]), "rt_set_overlap": (ci, [vp, ci]), "rt_set_tuning": (ci, [vp, cs, ci]),
-            "rt_stream_order": (ci, [vp, ci]), "rt_mark": (ci, [vp, ci, ci]), "rt_wait_mark": (ci, [vp, ci, ci]), "rt_mark_elapsed": (ci, [vp, ci, ci, C.POINTER(C.c_double)]), "rt_set_row_band": (ci, [vp, ci, ci]),
+            "rt_stream_order": (ci, [vp, ci]), "rt_mark": (ci, [vp, ci, ci]), "rt_wait_mark": (ci, [vp, ci, ci]),
+            "rt_debug_note_rows": (ci, [vp, ci, vp, vp, ci, ci, ci]),
+            "rt_debug_trace": (ci, [vp, ci]), "rt_debug_trace_dump": (C.c_int64, [vp, C.c_char_p, C.c_int64]), "rt_mark_elapsed": (ci, [vp, ci, ci, C.POINTER(C.c_double)]), "rt_set_row_band": (ci, [vp, ci, ci]),
             "rt_shader_open": (ci, [vp, cs, C.POINTER(vp)]), "rt_shader_close": (None, [vp]),
             "rt_find_kernel": (ci, [vp, cs]), "rt_dispatch": (ci, [vp, ci, ci, ci, ci]),
             "rt_dispatch_no_alloc": (ci, [vp, ci, ci, ci, ci]),
@@ -436,6 +438,16 @@ class RtContext:
     def set_tuning(self, name, value):
         """Speed-only implementation choices (see rt_set_tuning in include/rt_native.h)."""
         self.check(self.lib.rt_set_tuning(self.h, name.encode(), int(value)), f"rt_set_tuning({name})")
+
+    def trace(self, on):
+        """Starts (a new) or stops the log of launches, event records and waits (rt_debug_trace)."""
+        self.check(self.lib.rt_debug_trace(self.h, 1 if on else 0), "rt_debug_trace")
+
+    def trace_text(self):
+        need = self.lib.rt_debug_trace_dump(self.h, None, 0)
+        buf = C.create_string_buffer(int(need))
+        self.lib.rt_debug_trace_dump(self.h, buf, need)
+        return buf.value.decode()
 
     def set_overlap(self, mode):
         """0: off; 1: the next frame's primary rays run beside the previous frame's last kernels (whole-image

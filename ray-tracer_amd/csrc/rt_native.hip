@@ -140,6 +140,14 @@ struct rt_ctx_s {
     // one another in ways a quiet machine never shows: a missing wait between two launches then changes the image.
     // "debug_stream_delay_mask": which streams are held up - bit k: dispatch stream k, bit 7: the primary rays' stream
     // (default all).  Holding up ONE stream makes the others run ahead of it wherever nothing orders them.
+    // Test aid (rt_debug_trace): a log of what was put on which stream - every launch with the per-pixel objects it reads
+    // and writes, every event record and wait, every host operation on stream0 - from which a checker derives whether
+    // any two launches that touch the same memory, at least one of them writing, are ordered by the streams and events
+    // alone (tests/harness.py: launch_order_violations).  Timing plays no part in that.
+    struct TraceAccess { const void* obj; bool write; bool relaxed; int row0, row1; };   // image rows [row0, row1); row1 < 0: all of it
+    struct TraceOp { char kind; int stream; const void* event; const char* name; int nAcc; TraceAccess acc[16]; };
+    bool tracing = false;
+    std::vector<TraceOp> traceOps;
     int debugDelayUs = 0;
     int debugDelayMask = 0xff;
     uint32_t debugDelayState = 12345u;
@@ -273,6 +281,101 @@ int useDevice(rt_ctx ctx) {
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     return RT_OK;
 }
+int traceStreamIndex(rt_ctx ctx, hipStream_t s) {
+    for (int k = 0; k < MAX_FRAMES; k++) if (s == ctx->frameStream[k] && s) return k;
+    if (s == ctx->stream0) return 0;
+    if (s == ctx->stream1) return MAX_FRAMES;
+    if (s == ctx->transferStream) return MAX_FRAMES + 1;
+    return MAX_FRAMES + 2;
+}
+// Every event of the library that orders streams goes through these two (the timing events of LaunchScope do not).
+hipError_t evRecord(rt_ctx ctx, hipEvent_t ev, hipStream_t stream) {
+    if (ctx->tracing) ctx->traceOps.push_back({'R', traceStreamIndex(ctx, stream), (const void*)ev, "", 0, {}});
+    return hipEventRecord(ev, stream);
+}
+hipError_t evWait(rt_ctx ctx, hipStream_t stream, hipEvent_t ev) {
+    if (ctx->tracing) ctx->traceOps.push_back({'W', traceStreamIndex(ctx, stream), (const void*)ev, "", 0, {}});
+    return hipStreamWaitEvent(stream, ev, 0);
+}
+struct TraceLaunch {   // collects the accesses of one launch
+    rt_ctx_s::TraceOp op;
+    TraceLaunch(rt_ctx ctx, hipStream_t stream, const char* name) { op = {'L', traceStreamIndex(ctx, stream), nullptr, name, 0, {}}; }
+    int row0 = 0, row1 = -1;   // the rows the launch works on (a row band), for the accesses added with r() and w()
+    void add(const void* obj, bool write, bool relaxed = false, int r0 = 0, int r1 = -1) {
+        if (!obj || op.nAcc >= 16) return;
+        op.acc[op.nAcc++] = {obj, write, relaxed, r0, r1};
+    }
+    void r(const void* obj) { add(obj, false, false, row0, row1); }
+    void w(const void* obj) { add(obj, true, false, row0, row1); }
+    void rAround(const void* obj, int reach) { add(obj, false, false, row1 < 0 ? 0 : (row0 - reach > 0 ? row0 - reach : 0), row1 < 0 ? -1 : row1 + reach); }
+};
+// What a launch reads and writes, for the trace (rt_ctx_s::TraceOp).  `merged`: the launch also does the work of the
+// dispatch merged into it (TemporalReuse into the candidate kernel, TransferToOriginal into TraceRays); `acc`: and
+// AccumulateFrames.  The per-wave cost and step counts are relaxed accesses: k_order_blocks may read them while they are
+// being rewritten (it reads every count once, so its table is a complete one whatever it reads).
+void traceLaunch(rt_ctx ctx, hipStream_t stream, int ik, const KParams* Pp, bool merged, bool acc) {
+    if (!ctx->tracing) return;
+    TraceLaunch t(ctx, stream, IK_NAMES[ik]);
+    if (Pp) {
+        const KParams& P = *Pp;
+        t.add(P.blockMap, false);
+        if (P.row1 > P.row0) { t.row0 = P.row0; t.row1 = P.row1; }
+        switch (ik) {
+            case IK_PRIMARY:
+                t.w(P.hit.p0); t.w(P.depth.r); t.w(P.normals.rgba); t.w(P.debugOverlay.rgba);
+                t.w(P.FrameCount % 2 == 0 ? P.hitA.rgba : P.hitB.rgba);
+                t.add(P.blockCost, true, true);
+                break;
+            case IK_CANDIDATES:
+                t.r(P.hit.p0); t.w(P.cand.q);
+                if (merged) { t.r(P.depth.r); t.w(P.temporal.p0); t.r(P.hitA.rgba); t.r(P.hitB.rgba); }
+                break;
+            case IK_TEMPORAL:
+                t.w(P.cand.q); t.w(P.temporal.p0); t.r(P.depth.r); t.r(P.hitA.rgba); t.r(P.hitB.rgba);
+                break;
+            case IK_SPATIAL:
+                // (neighbours up to MaxOffset rows away, and one more row up: a negative x wraps into the row before)
+                t.rAround(P.ReuseBufferCycle ? P.cand.q : P.candB.q, P.MaxOffset + 1);
+                t.w(P.ReuseBufferCycle ? P.candB.q : P.cand.q);
+                t.rAround(P.depth.r, P.MaxOffset + 1);
+                break;
+            case IK_TRANSFER:
+                t.r(P.candB.q); t.w(P.cand.q); t.r(P.depth.r);
+                break;
+            case IK_TRACE_RAYS:
+                t.r(P.hit.p0); t.w(P.cand.q); t.w(P.result.rgba);
+                t.add(P.blockSteps, true, true);
+                if (merged) { t.r(P.candB.q); t.r(P.depth.r); }
+                if (acc) t.w(P.accumulated.rgba);
+                if (P.kwWeightRecalc) t.w(P.temporal.p0);
+                break;
+            case IK_ACCUMULATE:
+                t.r(P.result.rgba); t.w(P.accumulated.rgba);
+                break;
+            case IK_RIS_PRIMARY:
+                t.w(P.risHit); t.w(P.rayHitPoints.rgba); t.w(P.debugOverlay.rgba);
+                t.add(P.blockCost, true, true);
+                break;
+            case IK_RIS_CANDIDATES:
+                t.r(P.risHit); t.w(P.risCand);
+                break;
+            case IK_RIS_TRACE_RAYS:
+                t.r(P.risHit); t.r(P.risCand); t.w(P.result.rgba);
+                if (acc) t.w(P.accumulated.rgba);
+                break;
+            default: break;
+        }
+    }
+    ctx->traceOps.push_back(t.op);
+}
+void traceOrderBlocks(rt_ctx ctx, hipStream_t stream, const void* counts, const void* table) {
+    if (!ctx->tracing) return;
+    TraceLaunch t(ctx, stream, "order_blocks");
+    t.add(counts, false, true);
+    t.w(table);
+    ctx->traceOps.push_back(t.op);
+}
+
 // Checks the launch just made.  A failure is kept in the context (the first one wins) until finish() returns it: the
 // launch of a held dispatch happens inside a later call, possibly one that cannot return a status.
 void checkLaunch(rt_ctx ctx, const char* kernelName) {
@@ -308,7 +411,7 @@ hipStream_t frameStreamNow(rt_ctx ctx) {
     const int c = ctx->cur;
     if (c >= 1) {
         if (ctx->dirty[c]) {
-            if (hipEventRecord(ctx->evTail0, ctx->stream0) == hipSuccess && hipStreamWaitEvent(ctx->frameStream[c], ctx->evTail0, 0) == hipSuccess) ctx->dirty[c] = false;
+            if (evRecord(ctx, ctx->evTail0, ctx->stream0) == hipSuccess && evWait(ctx, ctx->frameStream[c], ctx->evTail0) == hipSuccess) ctx->dirty[c] = false;
         }
         ctx->ahead[c] = true;
     }
@@ -318,7 +421,7 @@ hipStream_t frameStreamNow(rt_ctx ctx) {
 void collapse(rt_ctx ctx) {
     for (int s = 1; s < MAX_FRAMES; s++) {
         if (!ctx->ahead[s]) continue;
-        if (hipEventRecord(ctx->evJoin[s], ctx->frameStream[s]) == hipSuccess && hipStreamWaitEvent(ctx->stream0, ctx->evJoin[s], 0) == hipSuccess) ctx->ahead[s] = false;
+        if (evRecord(ctx, ctx->evJoin[s], ctx->frameStream[s]) == hipSuccess && evWait(ctx, ctx->stream0, ctx->evJoin[s]) == hipSuccess) ctx->ahead[s] = false;
     }
 }
 bool anyPending(rt_ctx ctx) {
@@ -337,6 +440,8 @@ hipStream_t S(rt_ctx ctx) {
     if (ctx->held.kind) launchHeld(ctx);
     collapse(ctx);
     markDirty(ctx);
+    // (a host operation - a copy, a conversion, a scene rebuild - may touch anything)
+    if (ctx->tracing) ctx->traceOps.push_back({'H', 0, nullptr, "host", 0, {}});
     return ctx->stream0;
 }
 // Back to the one dispatch stream, behind everything (the start of a frame that will not run beside the one before).
@@ -349,13 +454,13 @@ void useMainStream(rt_ctx ctx) {
 void waitShared(rt_ctx ctx, int object, hipStream_t stream) {
     for (int s = 0; s < MAX_FRAMES; s++) {
         if (s == ctx->cur || !ctx->sharedValid[object][s]) continue;
-        hipError_t e = hipStreamWaitEvent(stream, ctx->evShared[object][s], 0);
+        hipError_t e = evWait(ctx, stream, ctx->evShared[object][s]);
         (void)e;
     }
 }
 void markShared(rt_ctx ctx, int object, hipStream_t stream) {
     if (ctx->framesInFlight < 2 || ctx->streamShared) { ctx->sharedValid[object][ctx->cur] = false; return; }
-    ctx->sharedValid[object][ctx->cur] = hipEventRecord(ctx->evShared[object][ctx->cur], stream) == hipSuccess;
+    ctx->sharedValid[object][ctx->cur] = evRecord(ctx, ctx->evShared[object][ctx->cur], stream) == hipSuccess;
 }
 // The stream of the frame being dispatched waits for all the other frame streams hold.
 void joinOthers(rt_ctx ctx) {
@@ -364,12 +469,12 @@ void joinOthers(rt_ctx ctx) {
         if (s == ctx->cur || !ctx->frameStream[s]) continue;
         if (s >= 1 && !ctx->ahead[s]) continue;   // (nothing there that stream0 is not already behind)
         if (!mine) mine = frameStreamNow(ctx);
-        if (hipEventRecord(ctx->evOther[s], ctx->frameStream[s]) == hipSuccess) { hipError_t e = hipStreamWaitEvent(mine, ctx->evOther[s], 0); (void)e; }
+        if (evRecord(ctx, ctx->evOther[s], ctx->frameStream[s]) == hipSuccess) { hipError_t e = evWait(ctx, mine, ctx->evOther[s]); (void)e; }
     }
 }
 void markAfterCandidates(rt_ctx ctx, hipStream_t stream) {
     if (!ctx->overlap || !ctx->behindCandidates || !ctx->evAfterCandidates) return;
-    ctx->afterCandidatesValid = hipEventRecord(ctx->evAfterCandidates, stream) == hipSuccess;
+    ctx->afterCandidatesValid = evRecord(ctx, ctx->evAfterCandidates, stream) == hipSuccess;
 }
 
 Planes planesOf(rt_buffer b) {
@@ -926,7 +1031,11 @@ void reorderBlocks(rt_ctx ctx, rt_ctx_s::BlockMap* m, bool primaryOnStream1) {
     if (m->dynValid && !firstMeasured && (++m->age % 8) != 0) return;
     m->rankedBySteps = measured;
     // the primary rays' cost follows the hit count, not the secondary rays' steps: their launch gets a ranking of its own
-    if (m->dynHits) hipLaunchKernelGGL(k_order_blocks, dim3(1), dim3(1024), 0, primaryOnStream1 ? ctx->stream1 : SK(ctx), m->cost, m->bx, m->by, m->dynHits, m->nDyn, 0);
+    if (m->dynHits) {
+        hipStream_t st = primaryOnStream1 ? ctx->stream1 : SK(ctx);
+        traceOrderBlocks(ctx, st, m->cost, m->dynHits);
+        hipLaunchKernelGGL(k_order_blocks, dim3(1), dim3(1024), 0, st, m->cost, m->bx, m->by, m->dynHits, m->nDyn, 0);
+    }
     m->pendingDyn = true;
     m->pendingMeasured = measured;
 }
@@ -938,11 +1047,12 @@ void reorderBlocksMain(rt_ctx ctx, rt_ctx_s::BlockMap* m) {
     // other stream's next launches behind the new table
     hipStream_t st = SK(ctx);
     joinOthers(ctx);
+    traceOrderBlocks(ctx, st, m->pendingMeasured ? m->steps : m->cost, m->dyn);
     hipLaunchKernelGGL(k_order_blocks, dim3(1), dim3(1024), 0, st, m->pendingMeasured ? m->steps : m->cost, m->bx, m->by, m->dyn, m->nDyn, m->pendingMeasured ? 1 : 0);
-    if (ctx->framesInFlight >= 2 && !ctx->streamShared && hipEventRecord(ctx->evTable, st) == hipSuccess) {
+    if (ctx->framesInFlight >= 2 && !ctx->streamShared && evRecord(ctx, ctx->evTable, st) == hipSuccess) {
         for (int k = 0; k < ctx->framesInFlight; k++) {
             if (k == ctx->cur) continue;
-            hipError_t e = hipStreamWaitEvent(ctx->frameStream[k], ctx->evTable, 0);
+            hipError_t e = evWait(ctx, ctx->frameStream[k], ctx->evTable);
             (void)e;
         }
     }
@@ -955,7 +1065,8 @@ struct LaunchScope {
     int ik;
     hipEvent_t start = nullptr, stop = nullptr;
     hipStream_t stream;
-    LaunchScope(rt_ctx c, int k, KParams* P, hipStream_t on = nullptr) : ctx(c), ik(k), stream(on ? on : SK(c)) {
+    LaunchScope(rt_ctx c, int k, KParams* P, hipStream_t on = nullptr, bool merged = false, bool acc = false) : ctx(c), ik(k), stream(on ? on : SK(c)) {
+        traceLaunch(ctx, stream, k, P, merged, acc);
         if (ctx->debugDelayUs > 0 && !ctx->noAlloc) {
             ctx->debugDelayState = ctx->debugDelayState * 1664525u + 1013904223u;
             const uint32_t r = ctx->debugDelayState >> 8;
@@ -1070,17 +1181,17 @@ bool beginOverlappedPrimary(rt_ctx ctx, const Flip* flips, int n, rt_buffer cons
     // everything enqueued so far uses (at most) the copies that are current now
     const uint64_t now = ctx->changes;
     const int rec = (int)(now % rt_ctx_s::BEFORE_RING);
-    if (hipEventRecord(ctx->evBefore[rec][0], ctx->stream0) != hipSuccess) return false;
+    if (evRecord(ctx, ctx->evBefore[rec][0], ctx->stream0) != hipSuccess) return false;
     ctx->beforeValid[rec][0] = true;
     for (int k = 1; k < MAX_FRAMES; k++) {
-        ctx->beforeValid[rec][k] = ctx->ahead[k] && hipEventRecord(ctx->evBefore[rec][k], ctx->frameStream[k]) == hipSuccess;
+        ctx->beforeValid[rec][k] = ctx->ahead[k] && evRecord(ctx, ctx->evBefore[rec][k], ctx->frameStream[k]) == hipSuccess;
         if (ctx->ahead[k] && !ctx->beforeValid[rec][k]) return false;
     }
     const int next = K > 1 ? (ctx->cur + 1) % K : ctx->cur;
     if (ctx->mainDirty) {  // something else went onto stream0: behind all of it, once
         collapse(ctx);
         if (anyPending(ctx)) return false;
-        if (hipEventRecord(ctx->evTail0, ctx->stream0) != hipSuccess || hipStreamWaitEvent(ctx->stream1, ctx->evTail0, 0) != hipSuccess) return false;
+        if (evRecord(ctx, ctx->evTail0, ctx->stream0) != hipSuccess || evWait(ctx, ctx->stream1, ctx->evTail0) != hipSuccess) return false;
         markDirty(ctx);   // (and so do the other frame streams, at their next launch)
         ctx->mainDirty = false;
     } else if (now + 1 >= (uint64_t)C) {
@@ -1089,11 +1200,11 @@ bool beginOverlappedPrimary(rt_ctx ctx, const Flip* flips, int n, rt_buffer cons
         const int old = (int)((now + 1 - (uint64_t)C) % rt_ctx_s::BEFORE_RING);
         for (int k = 0; k < MAX_FRAMES; k++) {
             if (!ctx->beforeValid[old][k]) continue;
-            if (hipStreamWaitEvent(ctx->stream1, ctx->evBefore[old][k], 0) != hipSuccess) return false;
-            if (k != next && hipStreamWaitEvent(ctx->frameStream[next], ctx->evBefore[old][k], 0) != hipSuccess) return false;
+            if (evWait(ctx, ctx->stream1, ctx->evBefore[old][k]) != hipSuccess) return false;
+            if (k != next && evWait(ctx, ctx->frameStream[next], ctx->evBefore[old][k]) != hipSuccess) return false;
         }
     }
-    if (ctx->behindCandidates && ctx->afterCandidatesValid && hipStreamWaitEvent(ctx->stream1, ctx->evAfterCandidates, 0) != hipSuccess) return false;
+    if (ctx->behindCandidates && ctx->afterCandidatesValid && evWait(ctx, ctx->stream1, ctx->evAfterCandidates) != hipSuccess) return false;
     ctx->changes = now + 1;
     ctx->cur = next;
     ctx->epoch++;
@@ -1108,8 +1219,8 @@ bool beginOverlappedPrimary(rt_ctx ctx, const Flip* flips, int n, rt_buffer cons
 }
 // After the overlapped launch: the frame's stream goes on only when the primary rays are done.
 int endOverlappedPrimary(rt_ctx ctx) {
-    HIP_TRY(ctx, hipEventRecord(ctx->evPrimary, ctx->stream1));
-    HIP_TRY(ctx, hipStreamWaitEvent(frameStreamNow(ctx), ctx->evPrimary, 0));
+    HIP_TRY(ctx, evRecord(ctx, ctx->evPrimary, ctx->stream1));
+    HIP_TRY(ctx, evWait(ctx, frameStreamNow(ctx), ctx->evPrimary));
     return RT_OK;
 }
 bool mayOverlap(rt_ctx ctx, bool instr, const KParams& P) {
@@ -1134,7 +1245,7 @@ void launchHeld(rt_ctx ctx, bool acc) {
     } else if (h.kind == 3) {
         if (acc) waitShared(ctx, rt_ctx_s::SH_TEMPORAL, st);
         {
-            LaunchScope ls(ctx, IK_CANDIDATES, &h.P, st);
+            LaunchScope ls(ctx, IK_CANDIDATES, &h.P, st, acc);
             if (acc) hipLaunchKernelGGL((k_candidates<false, true>), dim3(h.blocks), dim3(256), h.ldsBytes, st, h.P);
             else hipLaunchKernelGGL((k_candidates<false, false>), dim3(h.blocks), dim3(256), h.ldsBytes, st, h.P);
         }
@@ -1143,7 +1254,7 @@ void launchHeld(rt_ctx ctx, bool acc) {
     } else if (h.kind == 4) {
         waitShared(ctx, rt_ctx_s::SH_RESULT, st);
         {
-            LaunchScope ls(ctx, IK_RIS_TRACE_RAYS, &h.P, st);
+            LaunchScope ls(ctx, IK_RIS_TRACE_RAYS, &h.P, st, false, acc);
             if (acc) hipLaunchKernelGGL((k_ris_trace_rays<false, true>), dim3(h.blocks), dim3(256), h.ldsBytes, st, h.P);
             else hipLaunchKernelGGL((k_ris_trace_rays<false, false>), dim3(h.blocks), dim3(256), h.ldsBytes, st, h.P);
         }
@@ -1152,7 +1263,7 @@ void launchHeld(rt_ctx ctx, bool acc) {
         waitShared(ctx, rt_ctx_s::SH_RESULT, st);
         if (h.P.kwWeightRecalc) waitShared(ctx, rt_ctx_s::SH_TEMPORAL, st);   // (RS:645-657 writes into TemporalFrameBuffer)
         {
-            LaunchScope ls(ctx, IK_TRACE_RAYS, &h.P, st);
+            LaunchScope ls(ctx, IK_TRACE_RAYS, &h.P, st, h.withTransfer, acc);
             if (h.withTransfer && acc) hipLaunchKernelGGL((k_trace_rays<false, true, true>), dim3(h.blocks), dim3(256), h.ldsBytes, st, h.P);
             else if (h.withTransfer) hipLaunchKernelGGL((k_trace_rays<false, true, false>), dim3(h.blocks), dim3(256), h.ldsBytes, st, h.P);
             else if (acc) hipLaunchKernelGGL((k_trace_rays<false, false, true>), dim3(h.blocks), dim3(256), h.ldsBytes, st, h.P);
@@ -1678,6 +1789,7 @@ int rt_sync(rt_ctx ctx) {
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream0));
     for (int k = 1; k < MAX_FRAMES; k++) ctx->dirty[k] = false;   // nothing is left anywhere that a later launch would have to wait for
     if (ctx->transferStream) HIP_TRY(ctx, hipStreamSynchronize(ctx->transferStream));
+    if (ctx->tracing) ctx->traceOps.push_back({'Y', 0, nullptr, "sync", 0, {}});   // the host has waited for every stream
     return finish(ctx);
 }
 
@@ -1699,8 +1811,8 @@ int rt_stream_order(rt_ctx ctx, int first) {
     hipEvent_t& ev = ctx->orderEvent[first];
     if (!ev) HIP_TRY(ctx, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
     hipStream_t from = first == 0 ? SK(ctx) : ctx->transferStream, to = first == 0 ? ctx->transferStream : SK(ctx);
-    HIP_TRY(ctx, hipEventRecord(ev, from));
-    HIP_TRY(ctx, hipStreamWaitEvent(to, ev, 0));
+    HIP_TRY(ctx, evRecord(ctx, ev, from));
+    HIP_TRY(ctx, evWait(ctx, to, ev));
     return finish(ctx);
 }
 int rt_mark(rt_ctx ctx, int stream, int slot) {
@@ -1709,7 +1821,7 @@ int rt_mark(rt_ctx ctx, int stream, int slot) {
     if (rc) return rc;
     if (stream == 1 && !rt_transfer_stream(ctx)) return RT_ERR_NO_DEVICE;
     if (!ctx->marks[slot]) HIP_TRY(ctx, hipEventCreate(&ctx->marks[slot]));
-    HIP_TRY(ctx, hipEventRecord(ctx->marks[slot], stream == 0 ? SK(ctx) : ctx->transferStream));
+    HIP_TRY(ctx, evRecord(ctx, ctx->marks[slot], stream == 0 ? SK(ctx) : ctx->transferStream));
     return finish(ctx);
 }
 int rt_wait_mark(rt_ctx ctx, int stream, int slot) {
@@ -1718,7 +1830,7 @@ int rt_wait_mark(rt_ctx ctx, int stream, int slot) {
     int rc = useDevice(ctx);
     if (rc) return rc;
     if (stream == 1 && !rt_transfer_stream(ctx)) return RT_ERR_NO_DEVICE;
-    HIP_TRY(ctx, hipStreamWaitEvent(stream == 0 ? SK(ctx) : ctx->transferStream, ctx->marks[slot], 0));
+    HIP_TRY(ctx, evWait(ctx, stream == 0 ? SK(ctx) : ctx->transferStream, ctx->marks[slot]));
     return finish(ctx);
 }
 int rt_mark_elapsed(rt_ctx ctx, int a, int b, double* ms) {
@@ -1780,6 +1892,57 @@ int rt_set_tuning(rt_ctx ctx, const char* name, int value) {
     }
     else return fail(ctx, RT_ERR_INVALID_ARG, "unknown tuning parameter '%s'", name);
     return finish(ctx);
+}
+int rt_debug_trace(rt_ctx ctx, int on) {
+    if (!ctx) return RT_ERR_INVALID_ARG;
+    int rc = useDevice(ctx);
+    if (rc) return rc;
+    SK(ctx);
+    if (on) ctx->traceOps.clear();
+    ctx->tracing = on != 0;
+    return finish(ctx);
+}
+int rt_debug_note_rows(rt_ctx ctx, int stream, rt_buffer buf, rt_texture tex, int row0, int row1, int write) {
+    if (!ctx || stream < 0 || stream > 1 || (!buf && !tex) || row0 < 0 || row1 < row0) return RT_ERR_INVALID_ARG;
+    if ((buf && buf->ctx != ctx) || (tex && tex->ctx != ctx)) return RT_ERR_INVALID_ARG;
+    if (!ctx->tracing) return RT_OK;
+    TraceLaunch t(ctx, stream == 0 ? frameStreamNow(ctx) : ctx->transferStream, "transfer");
+    if (stream == 1) t.op.stream = MAX_FRAMES + 1;
+    if (buf) t.add(buf->dev, write != 0, false, row0, row1);
+    if (tex) t.add(tex->dev, write != 0, false, row0, row1);
+    ctx->traceOps.push_back(t.op);
+    return RT_OK;
+}
+int64_t rt_debug_trace_dump(rt_ctx ctx, void* out, int64_t capacity) {
+    if (!ctx || capacity < 0 || (!out && capacity)) return RT_ERR_INVALID_ARG;
+    std::string text;
+    char line[128];
+    for (const auto& op : ctx->traceOps) {
+        if (op.kind == 'L') {
+            snprintf(line, sizeof line, "L %d %s", op.stream, op.name);
+            text += line;
+            for (int i = 0; i < op.nAcc; i++) {
+                snprintf(line, sizeof line, " %p:%c%s", op.acc[i].obj, op.acc[i].write ? 'w' : 'r', op.acc[i].relaxed ? "~" : "");
+                text += line;
+                if (op.acc[i].row1 >= 0) { snprintf(line, sizeof line, ":%d-%d", op.acc[i].row0, op.acc[i].row1); text += line; }
+            }
+            text += "\n";
+        } else if (op.kind == 'H') {
+            text += "H 0\n";
+        } else if (op.kind == 'Y') {
+            text += "Y 0\n";
+        } else {
+            snprintf(line, sizeof line, "%c %d %p\n", op.kind, op.stream, op.event);
+            text += line;
+        }
+    }
+    const int64_t need = (int64_t)text.size() + 1;
+    if (out && capacity > 0) {
+        const int64_t n = need <= capacity ? need - 1 : capacity - 1;
+        memcpy(out, text.data(), (size_t)n);
+        ((char*)out)[n] = 0;
+    }
+    return need;
 }
 int rt_set_fusion(rt_ctx ctx, int enabled) {
     if (!ctx) return RT_ERR_INVALID_ARG;
@@ -1873,7 +2036,7 @@ int rt_dispatch_no_alloc(rt_shader sh, int kernel, int gx, int gy, int gz) {
     useMainStream(ctx);   // (enqueues two stream operations at most; allocates nothing)
     int rc = rt_dispatch(sh, kernel, gx, gy, gz);
     ctx->noAlloc = false;
-    { hipError_t e = hipEventRecord(ctx->noAllocDone, ctx->stream0); (void)e; }
+    { hipError_t e = evRecord(ctx, ctx->noAllocDone, ctx->stream0); (void)e; }
     return rc;
 }
 

@@ -558,6 +558,9 @@ struct rth_mg_s {
     std::vector<int> bounds;
     Rccl::comm_t comm = nullptr;
     bool timing = false;
+    // what the transfers of the plan being built read and write, for the library's log of stream operations (rt_debug_trace)
+    struct RowsNote { bool send; rt_buffer buf; rt_texture tex; int r0, r1; };
+    std::vector<RowsNote> notes;
     bool gatherPending = false;   // a frame has ended whose gather is not enqueued yet
     bool gatherStamped = false;   // MK_GATHER_DONE has been recorded
     double sums[RTH_MG_TIMES] = {};
@@ -762,6 +765,7 @@ void mgRows(rth_mg g, std::vector<rth_xfer>& plan, bool send, rt_buffer buf, rt_
     if (r1 <= r0) return;
     rt_segment seg[5];
     int cnt = 0;
+    g->notes.push_back({send, buf, tex, r0, r1});
     if (buf) mgCheck(g, rt_buffer_map_rows(buf, g->W, r0, r1, seg, &cnt), "rt_buffer_map_rows");
     if (tex) { mgCheck(g, rt_texture_map_rows(tex, r0, r1, &seg[cnt]), "rt_texture_map_rows"); cnt++; }
     for (int k = 0; k < cnt; k++) plan.push_back({send ? 1 : 0, peer, seg[k].ptr, seg[k].bytes});
@@ -769,6 +773,7 @@ void mgRows(rth_mg g, std::vector<rth_xfer>& plan, bool send, rt_buffer buf, rt_
 // The one halo exchange of a frame: my border rows of the first spatial pass's source buffer and of the depth buffer go
 // to both neighbours, theirs come here, `total` rows deep.
 void mgPlanHalo(rth_mg g, std::vector<rth_xfer>& plan) {
+    g->notes.clear();
     rth_main m = g->m;
     if (!m || g->iterations <= 0) return;
     const int rank = g->rank, world = g->world, H = g->H;
@@ -787,6 +792,7 @@ void mgPlanHalo(rth_mg g, std::vector<rth_xfer>& plan) {
 }
 // The displayed image is completed on rank 0.
 void mgPlanGather(rth_mg g, std::vector<rth_xfer>& plan) {
+    g->notes.clear();
     rt_texture result = g->m ? g->m->RTResultTexture.h : rth_ris_main_texture(g->ris, "Result");
     if (!result) throw DriverError{"the Result texture does not exist"};
     if (g->rank == 0) {
@@ -921,8 +927,14 @@ void hubRun(rth_mg g, const std::vector<rth_xfer>& plan) {
         hub->spent.push_back(rec->copied);
     }
 }
+void mgRunTransfers(rth_mg g, const std::vector<rth_xfer>& plan);
+// The transfers of the plan just built (mgPlanHalo / mgPlanGather), enqueued on the transfer stream.
 void mgRun(rth_mg g, const std::vector<rth_xfer>& plan) {
     if (plan.empty()) return;
+    mgRunTransfers(g, plan);
+    for (const auto& n : g->notes) mgCheck(g, rt_debug_note_rows(g->ctx, 1, n.buf, n.tex, n.r0, n.r1, n.send ? 0 : 1), "rt_debug_note_rows");
+}
+void mgRunTransfers(rth_mg g, const std::vector<rth_xfer>& plan) {
     if (g->hub) return hubRun(g, plan);
     auto nccl = [&](int rc, const char* what) { if (rc != 0) throw DriverError{std::string(what) + ": " + rccl().GetErrorString(rc)}; };
     void* stream = rt_transfer_stream(g->ctx);

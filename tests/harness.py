@@ -496,3 +496,68 @@ def quat(axis, deg, base):
     q = np.array([w1 * x2 + x1 * w2 + y1 * z2 - z1 * y2, w1 * y2 - x1 * z2 + y1 * w2 + z1 * x2,
                   w1 * z2 + x1 * y2 - y1 * x2 + z1 * w2, w1 * w2 - x1 * x2 - y1 * y2 - z1 * z2])
     return [float(np.float32(v)) for v in q / np.linalg.norm(q)]
+
+
+def launch_order_violations(trace_text, limit=20):
+    """Decides from a log of rt_debug_trace alone whether every two launches that touch the same object, at least one
+    of them writing, are ordered by stream order and event record -> wait edges (vector clocks; timing plays no part).
+    A host operation counts as touching everything.  Returns descriptions of the unordered pairs (at most `limit`)."""
+    n_streams = 8
+    clock = [[0] * n_streams for _ in range(n_streams)]      # per stream: what it is known to be behind
+    recorded = {}                                            # event -> clock at its last record
+    last = {}                                                # object -> the accesses that can still conflict with a later one
+    hosts = []                                               # host operations: (stream, tick, line number)
+    launches = []                                            # (stream, tick, line number, name): for host ops to check against
+    bad = []
+
+    def before(stream, tick, now):                           # did (stream, tick) happen before the op whose clock is `now`
+        return now[stream] >= tick
+
+    for ln, line in enumerate(trace_text.splitlines()):
+        f = line.split()
+        kind, s = f[0], int(f[1])
+        clock[s][s] += 1
+        if kind == "R":
+            recorded[f[2]] = list(clock[s])
+        elif kind == "W":
+            if f[2] in recorded:                             # (a wait for an event never recorded waits for nothing)
+                clock[s] = [max(a, b) for a, b in zip(clock[s], recorded[f[2]])]
+        elif kind == "Y":                                    # the host waited for everything: whatever follows is behind it all
+            merged = [max(c[k] for c in clock) for k in range(n_streams)]
+            clock = [list(merged) for _ in range(n_streams)]
+        elif kind == "H":
+            now = clock[s]
+            for (ls, lt, lln, name) in launches:
+                if not before(ls, lt, now):
+                    bad.append(f"line {ln}: host operation is not behind launch '{name}' (line {lln}, stream {ls})")
+            launches = []                                    # everything later is behind this operation or is reported below
+            hosts.append((s, clock[s][s], ln))
+        elif kind == "L":
+            now, name = clock[s], f[2]
+            for (hs, ht, hln) in hosts[-1:]:
+                if not before(hs, ht, now):
+                    bad.append(f"line {ln}: launch '{name}' on stream {s} is not behind the host operation of line {hln}")
+            for acc in f[3:]:
+                parts = acc.split(":")
+                obj, mode = parts[0], parts[1]
+                write, relaxed = mode[0] == "w", mode.endswith("~")
+                if relaxed:
+                    continue                                 # counts that may be read while rewritten (see rt_native.h)
+                r0, r1 = (int(x) for x in parts[2].split("-")) if len(parts) > 2 else (0, 1 << 30)
+                seen = last.setdefault(obj, [])
+                for (ps, pt, pw, p0, p1, what) in seen:
+                    if (write or pw) and p0 < r1 and r0 < p1 and not before(ps, pt, now):
+                        bad.append(f"line {ln}: '{name}' on stream {s} {'writes' if write else 'reads'} rows {r0}-{r1} of {obj} unordered against {what}")
+                # per object the accesses that can still matter: an access is forgotten once a later WRITE that is behind
+                # it covers its rows (whatever is behind that write is behind the access too); of the reads of one stream
+                # over the same rows only the latest is kept
+                entry = (s, clock[s][s], write, r0, r1, f"'{name}' (line {ln}, stream {s}, {'write' if write else 'read'} rows {r0}-{r1})")
+                if write:
+                    seen[:] = [e for e in seen if not (r0 <= e[3] and e[4] <= r1 and before(e[0], e[1], now))]
+                else:
+                    seen[:] = [e for e in seen if not (not e[2] and e[0] == s and e[3] == r0 and e[4] == r1)]
+                seen.append(entry)
+            launches.append((s, clock[s][s], ln, name))
+        if len(bad) >= limit:
+            break
+    return bad

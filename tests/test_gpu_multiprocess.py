@@ -291,7 +291,10 @@ def test_native_frame_loop_rehearsed_with_threads(scene_small, world, res, frame
     and the transfers the loop hands to RCCL go through the rehearsal hub instead (same matching and stream ordering,
     device copies).  All frames are enqueued without a wait in between - two to four frames in flight per rank, the gather of a
     frame behind the next frame's halo exchange - with a camera that moves from frame to frame, and a second call
-    continues the sequence.  Rank 0's gathered image and every rank's band must equal the single-GPU render."""
+    continues the sequence.  Rank 0's gathered image and every rank's band must equal the single-GPU render; and every
+    rank's log of the second call (rt_debug_trace: launches, the loop's transfers with their rows, event records and
+    waits) must show every two operations that touch the same rows of the same object, one of them writing, ordered
+    by streams and events alone (harness.launch_order_violations) - whatever the timing was."""
     import ctypes as C
     import threading
     import harness as h
@@ -355,10 +358,21 @@ def test_native_frame_loop_rehearsed_with_threads(scene_small, world, res, frame
             p = pos + np.float32(0.004 * part) * np.array([1, 0, 0.5], np.float32)
             for d in drvs:
                 d.set_camera(p, h.quat((0.2, 1, 0), 7.0 * part, rot))
+            if part == 1:      # the second call is also logged: launches, transfers, event records and waits of every rank
+                for c in ctxs[:world]:
+                    c.sync()
+                    c.trace(True)
             run(n)
             for _ in range(n):
                 ref.render_frame()
             check(f"call {part}")
+            if part == 1:
+                for r, c in enumerate(ctxs[:world]):
+                    c.trace(False)
+                    text = c.trace_text()
+                    assert "transfer" in text
+                    bad = h.launch_order_violations(text)
+                    assert not bad, f"rank {r}:\n" + "\n".join(bad)
     finally:
         for g in ranks:
             host.rth_mg_destroy(g)
