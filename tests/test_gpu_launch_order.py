@@ -107,3 +107,29 @@ def test_banded_frames_are_ordered(gpu_ctx, scene_small):
         gpu_ctx.set_row_band(0, 0)
         gpu_ctx.set_overlap(1)
         drv.close()
+
+
+def test_a_reload_between_frames_in_flight_is_ordered(gpu_ctx):
+    """Main.Update -> SetData while frames are in flight: the releases, uploads and the rebuilt traversal arrays are host
+    operations; everything launched before them must be behind them and everything after them behind them too."""
+    scene = rt.build_scene_s0(subdivide=False)
+    cfg = h.small_config(104, 72)
+    drv = rt.Driver(gpu_ctx, cfg, scene)
+    try:
+        for _ in range(3):
+            drv.render_frame()
+
+        def body():
+            for f in range(10):
+                if f == 4:
+                    scene.set_object_transform(1, (-3.0, -2.0, 12.0), (0.0, 25.0, 0.0), (12.0, 12.0, 12.0))
+                    scene.rebuild()
+                    drv.reload()
+                drv.render_frame()
+
+        text = traced(gpu_ctx, body)
+        assert text.count("\nH 0") > 10          # the reload's copies and conversions
+        bad = h.launch_order_violations(text)
+        assert not bad, "\n".join(bad)
+    finally:
+        drv.close()
