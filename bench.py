@@ -91,10 +91,11 @@ def pmc_file(W, H, small_scene, scene, project, extra=None):
     return os.path.join(ROOT, "profiles", f"r03_pmc_{tag}.json")
 
 
-def frames_in_flight_default():
-    """What new contexts start with (RT_FRAMES_IN_FLIGHT, else the library's default of 2)."""
-    e = os.environ.get("RT_FRAMES_IN_FLIGHT", "")
-    return max(1, min(4, int(e))) if e.isdigit() else 2
+def frames_in_flight_default(var="RT_FRAMES_IN_FLIGHT", default=2):
+    """What new contexts start with (the environment variable, else the library's default: 2 for the ReSTIR project's
+    frames, 3 for the RIS project's)."""
+    e = os.environ.get(var, "")
+    return max(1, min(4, int(e))) if e.isdigit() else default
 
 
 def pmc_profile(W, H, world, small_scene, scene, project, extra=None):
@@ -258,6 +259,7 @@ def main():
     if isolated:
         ctx.set_overlap(0)
         ctx.set_tuning("frames_in_flight", 1)
+        ctx.set_tuning("ris_frames_in_flight", 1)
         render(2)
         runner.sync()
     ctx.profile_reset()
@@ -269,6 +271,7 @@ def main():
     if isolated:
         ctx.set_overlap(1)
         ctx.set_tuning("frames_in_flight", frames_in_flight_default())
+        ctx.set_tuning("ris_frames_in_flight", frames_in_flight_default("RT_RIS_FRAMES_IN_FLIGHT", 3))
         render(4)   # back into the steady state of the mode that is timed
         runner.sync()
     if os.environ.get("RT_BENCH_DEBUG"):

@@ -112,6 +112,9 @@ int rt_set_overlap(rt_ctx ctx, int mode);
  *                                 dispatch streams (see rt_set_overlap; 3 and 4 measured no faster than 2); 1: one
  *                                 dispatch stream.  Setting 2 or more after rt_stream() tells the library that the
  *                                 host no longer uses that stream
+ *   "ris_frames_in_flight"       (RT_RIS_FRAMES_IN_FLIGHT, default 3) the same for the RIS project's frames, which are chained
+ *                                 through Result only (a copy of Candidates - 16 bytes x candidates per pixel - per frame
+ *                                 in flight): 0.664 / 0.640 / 0.622 / 0.640 ms per 1080p frame with 1 / 2 / 3 / 4
  *   "debug_stream_delay_us"      (default 0) test aid: before about every second launch its stream is held up for a
  *                                 pseudo-random time of up to this many microseconds (at most 2000), so that a missing
  *                                 order between launches of frames in flight shows as a wrong image

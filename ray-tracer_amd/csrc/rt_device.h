@@ -120,6 +120,7 @@ struct KParams {
     const rt_ris_material* risMats;
     rt_ris_hit_info* risHit; int64_t nRisHit;
     float4* risCand; int64_t nRisCand;
+    uint32_t* risTag; uint32_t risTagValue;   // per pixel ray, when the library keeps several copies of Candidates (see Recs)
     Tex rayHitPoints;
     int32_t RaysPerPixel, SceneObjectCandidatesNum, TriCandidatesNum, TotCandidatesNum, CandidateReservoirTestsNum;
     int32_t risMaxBounceCount, risMaxBVHDepth, risFrameRand;

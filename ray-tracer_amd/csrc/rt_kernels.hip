@@ -1530,19 +1530,25 @@ __global__ void k_recs_to_aos(Recs rc, OtherCopies others, float* aos, int64_t f
     r[6] = c.x; r[7] = c.y; r[8] = c.z; r[12] = c.w;
     r[9] = d.x;
 }
-// Makes the copy `rc` of a record buffer with several copies complete for records [first, first + n): a pixel whose
-// newest record is in another copy gets that record, and its tag.  (Run with no frame in flight.)
-__global__ void k_recs_merge(Recs rc, OtherCopies others, int64_t first, int64_t n) {
+// Makes the copy `rc` of a buffer with several copies complete for tagged groups [first, first + n): a group whose
+// newest contents are in another copy gets them, and the tag.  `group` = float4s per tag: 4 for a reservoir record, the
+// candidates of one pixel ray for the RIS project's Candidates.  (Run with no frame in flight.)
+__global__ void k_recs_merge(Recs rc, OtherCopies others, int64_t first, int64_t n, int group) {
     int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= n * 4) return;
-    const int64_t i = first + (j >> 2);
-    const int piece = (int)(j & 3);
+    if (j >= n * group) return;
+    const int64_t i = first + j / group;
+    const int piece = (int)(j % group);
     uint32_t t;
     const int from = newestCopy(rc, others, i, &t);
     if (from < 0) return;
-    rc.q[i * 4 + piece] = others.q[from][i * 4 + piece];
-    // (the four lanes of a record are neighbours in one wave: all have loaded the tags before this store is issued)
-    if (piece == 0) rc.tag[i] = t;
+    rc.q[i * group + piece] = others.q[from][i * group + piece];
+}
+// Second step: the tags (a kernel of its own: the threads of a large group are not all in one wave).
+__global__ void k_recs_merge_tags(Recs rc, OtherCopies others, int64_t first, int64_t n) {
+    int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    uint32_t t;
+    if (newestCopy(rc, others, first + j, &t) >= 0) rc.tag[first + j] = t;
 }
 // Rebuilds the workgroup -> block table with the heaviest 64x64-pixel regions first (longest-processing-time-first:
 // the launches that follow end with light regions instead of with a few heavy waves on an otherwise idle chip).

@@ -188,6 +188,7 @@ __global__ __launch_bounds__(256) void k_ris_candidates(const KParams P) {
         h = loadRisHit(P, (int64_t)rayIndex);
         hit = (int64_t)rayIndex < P.nRisHit && h.dst != INF();
     }
+    if (hit && P.risTag) P.risTag[rayIndex] = P.risTagValue;   // this copy now holds the pixel's newest candidates
     if (__builtin_amdgcn_ballot_w64(hit) != 0) {  // wave-uniform: the loops below are walked by the whole wave
         uint32_t state = idy * (uint32_t)P.ResX + idx + (uint32_t)P.risFrameRand;
         for (int i = 0; i < P.SceneObjectCandidatesNum; i++) {

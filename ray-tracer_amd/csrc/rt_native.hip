@@ -105,7 +105,9 @@ struct rt_ctx_s {
     // and the host has not asked for the dispatch stream itself (rt_stream: streamShared, one frame stream from then on).
     hipStream_t frameStream[MAX_FRAMES] = {};
     int cur = 0;
-    int framesInFlight = 2;        // 1..MAX_FRAMES dispatch streams in use
+    int framesInFlight = 2;        // 1..MAX_FRAMES dispatch streams the ReSTIR project's frames alternate between
+    int risFramesInFlight = 3;     // the same for the RIS project's frames (chained through Result only: 0.664 / 0.640 / 0.622 / 0.640 ms
+                                   // per 1080p frame with 1 / 2 / 3 / 4)
     bool streamShared = false;
     bool ahead[MAX_FRAMES] = {};     // [s >= 1] frameStream[s] holds work stream0 has not been made to wait for
     bool dirty[MAX_FRAMES] = {};     // [s >= 1] stream0 holds work frameStream[s] has not been made to wait for
@@ -236,6 +238,7 @@ struct rt_buffer_s {
     // frame that last wrote the pixel's record into that copy (see Recs).  A readback takes each pixel from the copy
     // with the larger tag.
     uint32_t* tag = nullptr;     // of the copy `dev` (those of the others: more.tag)
+    int tagGroup = 4;            // float4s per tag: a 64-byte reservoir record, or the candidates of one pixel ray (RIS)
     uint64_t epoch = 0;          // rt_ctx_s::epoch when the copies last changed places
 };
 
@@ -459,7 +462,7 @@ void waitShared(rt_ctx ctx, int object, hipStream_t stream) {
     }
 }
 void markShared(rt_ctx ctx, int object, hipStream_t stream) {
-    if (ctx->framesInFlight < 2 || ctx->streamShared) { ctx->sharedValid[object][ctx->cur] = false; return; }
+    if ((ctx->framesInFlight < 2 && ctx->risFramesInFlight < 2) || ctx->streamShared) { ctx->sharedValid[object][ctx->cur] = false; return; }
     ctx->sharedValid[object][ctx->cur] = evRecord(ctx, ctx->evShared[object][ctx->cur], stream) == hipSuccess;
 }
 // The stream of the frame being dispatched waits for all the other frame streams hold.
@@ -544,11 +547,14 @@ void dropCopies(rt_buffer b) {
 }
 // Completes the current copy of records [first, first + n) of a record buffer with several copies (all of them: n < 0),
 // on stream0 behind everything: afterwards that copy alone is what a single buffer would hold.
+int64_t tagCount(rt_buffer b) { return b->layout == LAYOUT_RESERVOIR_RECS ? b->count : b->count / b->tagGroup; }
 void mergeRecords(rt_buffer b, int64_t first = 0, int64_t n = -1) {
     if (!b->tag || b->more.n == 0) return;
-    if (n < 0) n = b->count - first;
+    if (n < 0) n = tagCount(b) - first;
     if (n <= 0) return;
-    hipLaunchKernelGGL(k_recs_merge, dim3((unsigned)((n * 4 + 255) / 256)), dim3(256), 0, S(b->ctx), recsOf(b), otherCopiesOf(b), first, n);
+    hipStream_t st = S(b->ctx);
+    hipLaunchKernelGGL(k_recs_merge, dim3((unsigned)((n * b->tagGroup + 255) / 256)), dim3(256), 0, st, recsOf(b), otherCopiesOf(b), first, n, b->tagGroup);
+    hipLaunchKernelGGL(k_recs_merge_tags, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, recsOf(b), otherCopiesOf(b), first, n);
 }
 // Before the host changes, or is given the address of, a per-pixel object the frames keep two copies of: which copy
 // holds a pixel's newest record follows from where the frames found hits, and that is what the host may now change.
@@ -1049,9 +1055,9 @@ void reorderBlocksMain(rt_ctx ctx, rt_ctx_s::BlockMap* m) {
     joinOthers(ctx);
     traceOrderBlocks(ctx, st, m->pendingMeasured ? m->steps : m->cost, m->dyn);
     hipLaunchKernelGGL(k_order_blocks, dim3(1), dim3(1024), 0, st, m->pendingMeasured ? m->steps : m->cost, m->bx, m->by, m->dyn, m->nDyn, m->pendingMeasured ? 1 : 0);
-    if (ctx->framesInFlight >= 2 && !ctx->streamShared && evRecord(ctx, ctx->evTable, st) == hipSuccess) {
-        for (int k = 0; k < ctx->framesInFlight; k++) {
-            if (k == ctx->cur) continue;
+    if (!ctx->streamShared && evRecord(ctx, ctx->evTable, st) == hipSuccess) {
+        for (int k = 0; k < MAX_FRAMES; k++) {
+            if (k == ctx->cur || !ctx->frameStream[k]) continue;
             hipError_t e = evWait(ctx, ctx->frameStream[k], ctx->evTable);
             (void)e;
         }
@@ -1160,19 +1166,20 @@ void rotateCopies(void** dev, uint32_t** tag, Copies& c) {
     *dev = oldest;
     if (tag) *tag = oldestTag;
 }
-bool beginOverlappedPrimary(rt_ctx ctx, const Flip* flips, int n, rt_buffer const* recs, int nRecs, bool alternate) {
+bool beginOverlappedPrimary(rt_ctx ctx, const Flip* flips, int n, rt_buffer const* recs, int nRecs, int frames) {
     if (!ctx->stream1 || !ctx->evPrimary) return false;
-    const int K = alternate && !ctx->streamShared ? ctx->framesInFlight : 1;   // frame streams this dispatch alternates between
+    const int K = ctx->streamShared || frames < 1 ? 1 : frames > MAX_FRAMES ? MAX_FRAMES : frames;   // frame streams this dispatch alternates between
     const int C = K > 2 ? K : 2;                                              // copies of what the primary rays overwrite
-    for (int k = 1; k < K; k++) if (!ctx->frameStream[k]) return false;
+    for (int k = 1; k < K; k++)
+        if (!ctx->frameStream[k] && hipStreamCreateWithFlags(&ctx->frameStream[k], hipStreamNonBlocking) != hipSuccess) { ctx->frameStream[k] = nullptr; return false; }
     for (int i = 0; i < n; i++)
         if (!ensureCopies(ctx, *flips[i].more, flips[i].bytes, C, nullptr, 0)) return false;
     for (int i = 0; i < nRecs; i++) {
         rt_buffer b = recs[i];
         if (!b || K < 2) continue;   // one frame stream: the records keep the copies they have
-        if (b->layout != LAYOUT_RESERVOIR_RECS) return false;
+        if (b->layout != LAYOUT_RESERVOIR_RECS && !(b->layout == LAYOUT_AOS && b->stride == 16)) return false;
         const bool fresh = !b->tag;
-        if (!ensureCopies(ctx, b->more, layoutBytes(b, b->layout), K, &b->tag, b->count)) {
+        if (!ensureCopies(ctx, b->more, layoutBytes(b, b->layout), K, &b->tag, tagCount(b))) {
             if (fresh) dropCopies(b);
             return false;
         }
@@ -1187,7 +1194,7 @@ bool beginOverlappedPrimary(rt_ctx ctx, const Flip* flips, int n, rt_buffer cons
         ctx->beforeValid[rec][k] = ctx->ahead[k] && evRecord(ctx, ctx->evBefore[rec][k], ctx->frameStream[k]) == hipSuccess;
         if (ctx->ahead[k] && !ctx->beforeValid[rec][k]) return false;
     }
-    const int next = K > 1 ? (ctx->cur + 1) % K : ctx->cur;
+    const int next = K > 1 ? (ctx->cur + 1) % K : 0;
     if (ctx->mainDirty) {  // something else went onto stream0: behind all of it, once
         collapse(ctx);
         if (anyPending(ctx)) return false;
@@ -1340,7 +1347,7 @@ int dispatchReSTIR(rt_shader sh, int kernel, int gx, int gy) {
                 if (bCandB && (bCandB->layout != LAYOUT_RESERVOIR_RECS || bCandB->count < npx)) bCandB = nullptr;
                 rt_buffer bCand = boundBuffer(sh, kernel, "Candidates");
                 rt_buffer const recs[2] = {bCand, bCandB == bCand ? nullptr : bCandB};
-                beside = mayOverlap(ctx, instr, P) && beginOverlappedPrimary(ctx, flips, 3, recs, 2, true);
+                beside = mayOverlap(ctx, instr, P) && beginOverlappedPrimary(ctx, flips, 3, recs, 2, ctx->framesInFlight);
                 if (beside) {
                     P.hit = planesOf(bHit);
                     P.depth.r = (float*)tDepth->dev;
@@ -1548,12 +1555,24 @@ int dispatchRIS(rt_shader sh, int kernel, int gx, int gy) {
         bool beside = false;
         {
             if (grid) P.blockCost = grid->cost;
-            // beside the kernels stream0 still holds of the frames before (rt_ctx_s::stream1): the RIS project's primary rays
-            // overwrite nothing but HitInfos that those still read
-            // (one frame stream: the RIS project's Candidates keep their single copy)
-            useMainStream(ctx);
+            // beside the kernels the frame streams still hold of the frames before (rt_ctx_s::stream1, frameStream): the RIS
+            // project's primary rays overwrite nothing but HitInfos that those still read, and with a copy of Candidates
+            // per frame in flight (tagged per pixel ray, like the reservoir records) GenerateCandidates of the next frame
+            // runs beside TraceRays of this one; only Result is shared
+            SK(ctx);
+            const int group = P.TotCandidatesNum > 0 ? P.TotCandidatesNum : 1;
+            if (cand->tag && cand->tagGroup != group) {   // another number of candidates per ray: the tags no longer fit
+                mergeRecords(cand);
+                HIP_TRY(ctx, hipStreamSynchronize(S(ctx)));
+                dropCopies(cand);
+            }
+            if (!cand->tag) cand->tagGroup = group;
+            rt_buffer const recs[1] = {cand->count % group == 0 && cand->layout == LAYOUT_AOS ? cand : nullptr};
             const Flip flips[1] = {{&hit->dev, &hit->more, hit->bytes}};
-            beside = mayOverlap(ctx, instr, P) && beginOverlappedPrimary(ctx, flips, 1, nullptr, 0, false);
+            beside = mayOverlap(ctx, instr, P) && beginOverlappedPrimary(ctx, flips, 1, recs, 1, ctx->risFramesInFlight);
+            if (!beside) useMainStream(ctx);
+            P.risCand = (float4*)cand->dev;
+            P.risTag = cand->tag; P.risTagValue = (uint32_t)ctx->epoch;
             if (beside) P.risHit = (rt_ris_hit_info*)hit->dev;
             {
                 LaunchScope ls(ctx, IK_RIS_PRIMARY, &P, beside ? ctx->stream1 : nullptr);
@@ -1570,6 +1589,7 @@ int dispatchRIS(rt_shader sh, int kernel, int gx, int gy) {
             blocks = grid->nDyn;
             P.blockCost = nullptr;
         }
+        if (cand->epoch != ctx->epoch) joinOthers(ctx);   // Candidates without a copy for this frame: behind the frame before
         {
             LaunchScope ls(ctx, IK_RIS_CANDIDATES, &P);
             hipLaunchKernelGGL(k_ris_candidates, dim3(blocks), dim3(256), 0, ls.stream, P);
@@ -1579,6 +1599,7 @@ int dispatchRIS(rt_shader sh, int kernel, int gx, int gy) {
     } else {
         if ((rc = needTex(sh, kernel, "Result", false, X, Y, P.result))) return rc;
         if (!blocks) return RT_OK;
+        if (cand->epoch != ctx->epoch) joinOthers(ctx);
         if (mayHold(ctx, instr)) {  // held: an AccumulateFrames that follows becomes part of the launch
             SK(ctx);
             ctx->held.kind = 4; ctx->held.P = P; ctx->held.blocks = blocks; ctx->held.ldsBytes = ldsBytes; ctx->held.grid = grid;
@@ -1715,6 +1736,8 @@ int rt_create(int device_id, rt_ctx* out) {
         if (!lowPriority || hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) least = 0;
         static const int inFlight = [] { const char* e = getenv("RT_FRAMES_IN_FLIGHT"); return e ? atoi(e) : 2; }();
         ctx->framesInFlight = inFlight < 1 ? 1 : inFlight > MAX_FRAMES ? MAX_FRAMES : inFlight;
+        static const int risInFlight = [] { const char* e = getenv("RT_RIS_FRAMES_IN_FLIGHT"); return e ? atoi(e) : 3; }();
+        ctx->risFramesInFlight = risInFlight < 1 ? 1 : risInFlight > MAX_FRAMES ? MAX_FRAMES : risInFlight;
         ctx->frameStream[0] = ctx->stream0;
         bool ok = hipStreamCreateWithPriority(&ctx->stream1, hipStreamNonBlocking, least) == hipSuccess;
         // (the third and fourth dispatch stream are made when they are asked for: a process has few hardware queues -
@@ -1881,6 +1904,13 @@ int rt_set_tuning(rt_ctx ctx, const char* name, int value) {
     else if (!strcmp(name, "overlap_behind_candidates")) { ctx->behindCandidates = value != 0; ctx->afterCandidatesValid = false; markDirty(ctx); }
     else if (!strcmp(name, "debug_stream_delay_us")) ctx->debugDelayUs = value < 0 ? 0 : value > 2000 ? 2000 : value;
     else if (!strcmp(name, "debug_stream_delay_mask")) ctx->debugDelayMask = value & 0xff;
+    else if (!strcmp(name, "ris_frames_in_flight")) {
+        if (value < 1 || value > MAX_FRAMES) return fail(ctx, RT_ERR_INVALID_ARG, "ris_frames_in_flight must be 1 to %d", MAX_FRAMES);
+        useMainStream(ctx);
+        ctx->risFramesInFlight = value;
+        if (value >= 2) ctx->streamShared = false;
+        markDirty(ctx);
+    }
     else if (!strcmp(name, "frames_in_flight")) {
         if (value < 1 || value > MAX_FRAMES) return fail(ctx, RT_ERR_INVALID_ARG, "frames_in_flight must be 1 to %d", MAX_FRAMES);
         useMainStream(ctx);
@@ -2113,6 +2143,11 @@ int rt_buffer_set_data(rt_buffer b, const void* src, size_t bytes) {
     int rc = useDevice(ctx);
     if (rc) return rc;
     if (b->more.n && !b->tag) settleRecords(ctx);
+    if (b->tag && b->layout == LAYOUT_AOS) {   // copies of a buffer that is kept in the ABI layout: back to one
+        mergeRecords(b);
+        HIP_TRY(ctx, hipStreamSynchronize(S(ctx)));
+        dropCopies(b);
+    }
     if ((rc = convertLayout(b, LAYOUT_AOS))) return rc;
     // synchronous copy: the caller may reuse `src` as soon as this returns
     HIP_TRY(ctx, hipMemcpyAsync(b->dev, src, bytes, hipMemcpyHostToDevice, S(ctx)));
@@ -2128,6 +2163,7 @@ int rt_buffer_get_data(rt_buffer b, void* dst, size_t bytes) {
     int rc = useDevice(ctx);
     if (rc) return rc;
     if (b->layout == LAYOUT_AOS) {
+        mergeRecords(b);   // (the RIS project's Candidates with a copy per frame in flight: the current copy made complete)
         HIP_TRY(ctx, hipMemcpyAsync(dst, b->dev, bytes, hipMemcpyDeviceToHost, S(ctx)));
         HIP_TRY(ctx, hipStreamSynchronize(S(ctx)));
         return finish(ctx);
@@ -2154,6 +2190,7 @@ int rt_buffer_get_range(rt_buffer b, void* dst, int64_t first, int64_t count) {
     if (rc) return rc;
     const size_t bytes = (size_t)count * b->stride;
     if (b->layout == LAYOUT_AOS) {
+        mergeRecords(b);
         HIP_TRY(ctx, hipMemcpyAsync(dst, (const char*)b->dev + (size_t)first * b->stride, bytes, hipMemcpyDeviceToHost, S(ctx)));
         HIP_TRY(ctx, hipStreamSynchronize(S(ctx)));
         return finish(ctx);
@@ -2300,7 +2337,8 @@ int rt_buffer_map_rows(rt_buffer b, int width, int row0, int row1, rt_segment ou
     // one another (overlap 2, where the rows a band does not own are undefined in such objects anyway), that copy is
     // first made to hold what a single buffer would.
     if (ctx->overlap != 2) {
-        if (b->tag) mergeRecords(b, (int64_t)first, (int64_t)n);
+        if (b->tag && b->layout == LAYOUT_RESERVOIR_RECS) mergeRecords(b, (int64_t)first, (int64_t)n);
+        else if (b->tag) mergeRecords(b);
         else if (b->more.n) settleRecords(ctx);
     }
     char* base = (char*)b->dev;
@@ -2326,7 +2364,9 @@ int rt_buffer_rows_written(rt_buffer b, int width, int row0, int row1) {
     if (rc) return rc;
     if (!b->tag || row1 == row0) return finish(ctx);
     // (only the frames that work on this copy write its tags, and they do so on this stream or behind it)
-    HIP_TRY(ctx, hipMemsetD32Async((hipDeviceptr_t)(b->tag + (size_t)row0 * width), (int)(uint32_t)ctx->epoch, (size_t)(row1 - row0) * width, SK(ctx)));
+    const size_t per = b->layout == LAYOUT_RESERVOIR_RECS ? 1 : (size_t)b->tagGroup;   // records per tag
+    const size_t t0 = (size_t)row0 * width / per, t1 = ((size_t)row1 * width + per - 1) / per;
+    HIP_TRY(ctx, hipMemsetD32Async((hipDeviceptr_t)(b->tag + t0), (int)(uint32_t)ctx->epoch, t1 - t0, SK(ctx)));
     return finish(ctx);
 }
 int rt_texture_map_rows(rt_texture t, int row0, int row1, rt_segment* out) {

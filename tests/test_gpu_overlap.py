@@ -135,10 +135,11 @@ def test_unsynchronised_frames_against_the_oracle(gpu_ctx, scene_small, in_fligh
         drv.close()
 
 
-@pytest.mark.parametrize("delay_us", [0, 100])
-def test_ris_frames_overlap_and_match(gpu_ctx, scene_small, delay_us):
+@pytest.mark.parametrize("delay_us,in_flight", [(0, 3), (100, 3), (150, 2), (0, 1), (120, 4)])
+def test_ris_frames_overlap_and_match(gpu_ctx, scene_small, delay_us, in_flight):
     cfg = h.small_ris_config(120, 88)
     gpu_ctx.set_tuning("debug_stream_delay_us", delay_us)
+    gpu_ctx.set_tuning("ris_frames_in_flight", in_flight)
     drv = rt.RisDriver(gpu_ctx, cfg, scene_small)
     orc = h.RisOracleRenderer(scene_small.arrays(), cfg)
     try:
@@ -149,7 +150,7 @@ def test_ris_frames_overlap_and_match(gpu_ctx, scene_small, delay_us):
             drv.run_stage(1); orc.trace_rays()
             assert np.array_equal(h.bits(drv.buffer("HitInfos")), h.bits(orc.buf["HitInfos"])), f"frame {f}"
             drv.run_post_processing(); orc.accumulate()
-        for _ in range(3):
+        for _ in range(7):
             drv.render_frame(); orc.render_frame()
         for k in ("HitInfos", "Candidates"):
             assert np.array_equal(h.bits(drv.buffer(k)), h.bits(orc.buf[k])), k
@@ -157,6 +158,7 @@ def test_ris_frames_overlap_and_match(gpu_ctx, scene_small, delay_us):
             assert np.array_equal(h.bits(drv.texture(k)), h.bits(orc.tex[k])), k
     finally:
         gpu_ctx.set_tuning("debug_stream_delay_us", 0)
+        gpu_ctx.set_tuning("ris_frames_in_flight", 3)
         drv.close()
 
 
@@ -292,3 +294,34 @@ def test_weight_recalc_orders_the_frames_in_flight(gpu_ctx, scene_small):
             assert np.array_equal(h.bits(drv.texture(k)), h.bits(orc.tex[k])), k
     finally:
         drv.close()
+
+
+@pytest.mark.parametrize("in_flight", [2, 3, 4])
+def test_ris_candidates_read_back_from_the_copy_that_holds_them(gpu_ctx, scene_small, in_flight):
+    """The RIS project's Candidates get a copy per frame in flight, tagged per pixel ray.  Frames that render different
+    row bands leave every pixel's newest candidates in whichever copy the last frame that covered it wrote: the
+    readback has to pick per pixel, and equals what one buffer holds when the same frames run one after the other."""
+    cfg = h.small_ris_config(96, 80)
+    bands = [(0, 48), (32, 80), (16, 64), (0, 80), (40, 80), (0, 24), (8, 72)]
+    got = {}
+    try:
+        for mode in ("serial", "in flight"):
+            gpu_ctx.set_overlap(0 if mode == "serial" else 2)
+            gpu_ctx.set_tuning("ris_frames_in_flight", 1 if mode == "serial" else in_flight)
+            drv = rt.RisDriver(gpu_ctx, cfg, scene_small)
+            for b in bands:
+                gpu_ctx.set_row_band(*b)
+                drv.render_frame()
+            gpu_ctx.set_row_band(0, 0)
+            got[mode] = drv.buffer("Candidates")
+            if mode == "in flight":   # an upload makes one copy of them again, and the frames go on
+                gpu_ctx.set_buffer_data(drv.buffer_handle("Candidates"), got[mode])
+                drv.render_frame(); drv.render_frame()
+                gpu_ctx.sync()
+            drv.close()
+        assert np.array_equal(h.bits(got["serial"]), h.bits(got["in flight"]))
+        assert np.any(h.bits(got["serial"]))
+    finally:
+        gpu_ctx.set_row_band(0, 0)
+        gpu_ctx.set_overlap(1)
+        gpu_ctx.set_tuning("ris_frames_in_flight", 3)
