@@ -977,7 +977,10 @@ int rth_mg_render_frames(rth_mg g, int n) {
         std::vector<rth_xfer> plan;
         // (a communicator of one rank has nothing to transfer, but takes the same path through the loop)
         const bool multi = g->world > 1 || g->comm || g->hub;
-        const bool pipelined = multi && !g->timing;
+        // (RTH_MG_PIPELINE=0 in the environment - of every rank - keeps the gather of a frame ahead of the next frame's halo
+        // exchange, as with the per-step timing: the order for narrowing down a problem on new hardware)
+        static const bool pipelineAllowed = [] { const char* e = getenv("RTH_MG_PIPELINE"); return e ? atoi(e) != 0 : true; }();
+        const bool pipelined = multi && !g->timing && pipelineAllowed;
         auto gather = [&] {
             plan.clear();
             mgPlanGather(g, plan);
