@@ -171,6 +171,8 @@ def main():
     ap.add_argument("--exchange", choices=("rccl", "torch"), default="rccl",
                     help="N > 1: halo exchange from the C++ frame loop with RCCL calls (default), or from Python with "
                          "torch.distributed's NCCL backend")
+    ap.add_argument("--tuning", action="append", default=[], metavar="NAME=VALUE",
+                    help="rt_set_tuning(NAME, VALUE) before the first frame (experiments; repeatable)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -236,6 +238,9 @@ def main():
 
     ctx = runner.ctx
     ctx.enable_stats(1)
+    for item in args.tuning:
+        name, _, value = item.partition("=")
+        ctx.set_tuning(name, int(value))
 
     def render(n):
         # the native multi-GPU loop takes the whole run of frames in one call: it keeps the gather of a frame behind the

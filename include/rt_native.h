@@ -115,6 +115,12 @@ int rt_set_overlap(rt_ctx ctx, int mode);
  *   "ris_frames_in_flight"       (RT_RIS_FRAMES_IN_FLIGHT, default 3) the same for the RIS project's frames, which are chained
  *                                 through Result only (a copy of Candidates - 16 bytes x candidates per pixel - per frame
  *                                 in flight): 0.664 / 0.640 / 0.622 / 0.640 ms per 1080p frame with 1 / 2 / 3 / 4
+ *   "region_blocks_rays"         (default 2)  1, 2, 4 or 8: side, in 16x16-pixel blocks, of the image regions that the
+ *   "region_blocks_reuse"        (default 4)  heaviest-first workgroup tables move as a whole - for the kernels that cast
+ *   "region_blocks_primary"      (default 4)  secondary rays, for the reuse / copy / accumulate kernels, and for the primary
+ *                                 rays.  Doubled while an image has more than 8192 regions of that size.  Setting one waits
+ *                                 for the context's work and rebuilds the tables (1080p: 0.697 ms per frame with 4 / 4 / 4,
+ *                                 0.686 with 2 for the secondary rays; 4K: 2.436 and 2.407 ms)
  *   "debug_stream_delay_us"      (default 0) test aid: before about every second launch its stream is held up for a
  *                                 pseudo-random time of up to this many microseconds (at most 2000), so that a missing
  *                                 order between launches of frames in flight shows as a wrong image

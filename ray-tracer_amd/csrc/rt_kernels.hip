@@ -1550,22 +1550,29 @@ __global__ void k_recs_merge_tags(Recs rc, OtherCopies others, int64_t first, in
     uint32_t t;
     if (newestCopy(rc, others, first + j, &t) >= 0) rc.tag[first + j] = t;
 }
-// Rebuilds the workgroup -> block table with the heaviest 64x64-pixel regions first (longest-processing-time-first:
-// the launches that follow end with light regions instead of with a few heavy waves on an otherwise idle chip).
-// Regions are ranked by their hit pixels in steps of 64 (a counting sort; the order inside a step is whatever the
-// atomics give: any permutation renders the same image) and dealt to the 8 XCDs in that order; every XCD still walks
-// whole regions.  One workgroup; `dyn` has ceil(regions / 8) * 128 entries.
+// Rebuilds the workgroup -> block table with the heaviest regions first (longest-processing-time-first: the launches
+// that follow end with light regions instead of with a few heavy waves on an otherwise idle chip).
+// Regions (RS x RS blocks; 64x64 pixels at RS = 4) are ranked by their hit pixels in steps of 64 (a counting sort; the
+// order inside a step is whatever the atomics give: any permutation renders the same image) and dealt to the 8 XCDs in
+// that order; every XCD still walks whole regions.  One workgroup per table: workgroup b writes `out.t[b]`, which has
+// ceil(regions / 8) * 8 * RS * RS entries, from the same counts.
 #ifndef RT_REGION
-#define RT_REGION 4   // blocks per side of a region
+#define RT_REGION 4   // blocks per side of a region, where nothing else is asked for
 #endif
-constexpr int ORDER_MAX_REGIONS = 4096;
+constexpr int ORDER_MAX_REGIONS = 8192;   // (57 KB of LDS in k_order_blocks)
+struct OrderTables {
+    struct { uint32_t* dyn; unsigned nDyn; int rs; } t[2];
+};
 // byMax = 0: costW holds hit pixels per wave, a region's rank is their sum in steps of 64; byMax = 1: costW holds the
 // steps each wave needed for its secondary rays, a region's rank is its longest wave in steps of 8 (the waves with the
 // longest rays must start first: a wave cannot end before its longest ray does).
-__global__ __launch_bounds__(1024) void k_order_blocks(const uint32_t* costW, int BX, int BY, uint32_t* dyn, unsigned nDyn, int byMax) {
-    __shared__ uint32_t hist[66], order[ORDER_MAX_REGIONS], regionCost[ORDER_MAX_REGIONS];
+__global__ __launch_bounds__(1024) void k_order_blocks(const uint32_t* costW, int BX, int BY, OrderTables out, int byMax) {
+    __shared__ uint32_t hist[66], regionCost[ORDER_MAX_REGIONS];
+    __shared__ uint16_t order[ORDER_MAX_REGIONS];
     __shared__ uint8_t bucketOf[ORDER_MAX_REGIONS];
-    constexpr int RS = RT_REGION;
+    uint32_t* const dyn = out.t[blockIdx.x].dyn;
+    const unsigned nDyn = out.t[blockIdx.x].nDyn;
+    const int RS = out.t[blockIdx.x].rs;
     const int RX = (BX + RS - 1) / RS, RY = (BY + RS - 1) / RS, R = RX * RY;
     const int t = (int)threadIdx.x;
     if (t < 66) hist[t] = 0;
@@ -1590,7 +1597,7 @@ __global__ __launch_bounds__(1024) void k_order_blocks(const uint32_t* costW, in
         for (int b = 0; b < 65; b++) { const uint32_t n = hist[b]; hist[b] = run; run += n; }
     }
     __syncthreads();
-    for (int r = t; r < R; r += 1024) order[atomicAdd(&hist[bucketOf[r]], 1u)] = (uint32_t)r;
+    for (int r = t; r < R; r += 1024) order[atomicAdd(&hist[bucketOf[r]], 1u)] = (uint16_t)r;
     __syncthreads();
     for (unsigned m = (unsigned)t; m < nDyn; m += 1024) {
         const unsigned xcd = m % 8, j = m / 8, ord = (j / (RS * RS)) * 8 + xcd, k = j % (RS * RS);

@@ -42,7 +42,8 @@ const char* const IK_NAMES[IK_COUNT] = {"primary", "candidates", "temporal", "sp
 // hit counts the table is ranked by (COST words).  File scope, so it exists once per GPU for the life of the process;
 // `scratch` itself is only a host-side handle: the device address is taken once per device with hipGetSymbolAddress
 // (rt_create) and every use below goes through that pointer.
-constexpr unsigned NOALLOC_MAX_REGIONS = ORDER_MAX_REGIONS;                                    // 64x64-pixel regions per launch
+constexpr unsigned NOALLOC_MAX_REGIONS = 4096;                                                 // 64x64-pixel regions per launch
+static_assert(NOALLOC_MAX_REGIONS <= (unsigned)ORDER_MAX_REGIONS, "the ordering kernel must hold the scratch table's regions");
 constexpr size_t NOALLOC_TABLE_WORDS = (size_t)NOALLOC_MAX_REGIONS * RT_REGION * RT_REGION;    // one word per 16x16-pixel block
 constexpr size_t NOALLOC_COST_WORDS = NOALLOC_TABLE_WORDS * 4;                                 // one word per 8x8-pixel tile
 static __device__ __align__(256) uint32_t scratch[NOALLOC_TABLE_WORDS + NOALLOC_COST_WORDS];   // 1.25 MiB
@@ -166,8 +167,17 @@ struct rt_ctx_s {
     // dev: the static order; dyn: the heaviest-first order k_order_blocks rebuilds after InitialTrace's primary rays, from the
     // per-wave hit counts in cost until a TraceRays has run on this grid, then from the steps its waves needed (steps);
     // null when the grid has more regions than that kernel sorts
-    struct BlockMap { int bx, by; uint32_t* dev; unsigned n; uint32_t* dyn; uint32_t* cost; unsigned nDyn; bool dynValid; unsigned age; uint32_t* steps; bool stepsValid; bool rankedBySteps; uint32_t* dynHits; bool pendingDyn; bool pendingMeasured; };
+    struct BlockMap { int bx, by; uint32_t* dev; unsigned n; uint32_t* dyn; uint32_t* cost; unsigned nDyn; bool dynValid; unsigned age; uint32_t* steps; bool stepsValid; bool rankedBySteps; uint32_t* dynHits; bool pendingDyn; bool pendingMeasured;
+                      // region sizes (blocks per side) of the three heaviest-first tables, and the tables that differ from `dyn`:
+                      // dynHits (ranked by hit pixels: the primary rays) and dynRays (ranked by steps like dyn: the kernels that
+                      // cast secondary rays; the same pointer as dyn when the region sizes are equal)
+                      int rs, rsHits, rsRays; unsigned nDynHits; uint32_t* dynRays; unsigned nDynRays; };
     std::vector<BlockMap> blockMaps;  // one per band height in use (a multi-GPU host alternates between a few)
+    // Blocks per side of a region in the heaviest-first tables of [0] the reuse, copy and accumulate kernels, [1] the
+    // primary rays, [2] the kernels that cast secondary rays (tuning "region_blocks_reuse" / "_primary" / "_rays").
+    // Large regions keep an XCD's L2 on one part of the image and of the BVH; small ones let the heaviest-first order
+    // balance the XCDs more finely, which is what the secondary rays (few, long, uneven) gain from.
+    int regionBlocks[3] = {RT_REGION, RT_REGION, 2};
     uint32_t* scratch = nullptr;  // this device's address of the file-scope `scratch` array
     bool noAlloc = false;         // set for the duration of rt_dispatch_no_alloc
     BlockMap noAllocMap = {};     // the table of the launch in flight when noAlloc is set (lives in `scratch`)
@@ -371,11 +381,12 @@ void traceLaunch(rt_ctx ctx, hipStream_t stream, int ik, const KParams* Pp, bool
     }
     ctx->traceOps.push_back(t.op);
 }
-void traceOrderBlocks(rt_ctx ctx, hipStream_t stream, const void* counts, const void* table) {
+void traceOrderBlocks(rt_ctx ctx, hipStream_t stream, const void* counts, const void* table, const void* table2 = nullptr) {
     if (!ctx->tracing) return;
     TraceLaunch t(ctx, stream, "order_blocks");
     t.add(counts, false, true);
     t.w(table);
+    if (table2) t.w(table2);
     ctx->traceOps.push_back(t.op);
 }
 
@@ -980,7 +991,10 @@ int pixelGrid(rt_ctx ctx, KParams& P, int gx, int gy, unsigned* blocks, rt_ctx_s
         m.dynValid = false; m.age = 0;
         HIP_TRY(ctx, hipMemsetAsync(m.cost, 0, (size_t)bx * by * 4 * sizeof(uint32_t), S(ctx)));
         m.steps = nullptr; m.stepsValid = false; m.rankedBySteps = false; m.dynHits = nullptr; m.pendingDyn = false; m.pendingMeasured = false;
-        hipLaunchKernelGGL(k_order_blocks, dim3(1), dim3(1024), 0, S(ctx), m.cost, m.bx, m.by, m.dyn, m.nDyn, 0);
+        m.rs = m.rsHits = m.rsRays = RT_REGION; m.nDynHits = 0; m.dynRays = m.dyn; m.nDynRays = m.nDyn;   // one table for every kernel
+        OrderTables one = {};
+        one.t[0].dyn = m.dyn; one.t[0].nDyn = m.nDyn; one.t[0].rs = RT_REGION;
+        hipLaunchKernelGGL(k_order_blocks, dim3(1), dim3(1024), 0, S(ctx), m.cost, m.bx, m.by, one, 0);
         LAUNCH_TRY(ctx, "order_blocks");
         P.blockMap = m.dev;
         *blocks = m.n;
@@ -1003,6 +1017,7 @@ int pixelGrid(rt_ctx ctx, KParams& P, int gx, int gy, unsigned* blocks, rt_ctx_s
         if (old.cost) e = hipFree(old.cost);
         if (old.steps) e = hipFree(old.steps);
         if (old.dynHits) e = hipFree(old.dynHits);
+        if (old.dynRays && old.dynRays != old.dyn) e = hipFree(old.dynRays);
         (void)e;
         ctx->blockMaps.erase(ctx->blockMaps.begin());
     }
@@ -1010,18 +1025,44 @@ int pixelGrid(rt_ctx ctx, KParams& P, int gx, int gy, unsigned* blocks, rt_ctx_s
     rt_ctx_s::BlockMap m = {(int)bx, (int)by, nullptr, (unsigned)map.size(), nullptr, nullptr, 0, false, 0, nullptr, false, false, nullptr, false, false};
     HIP_TRY(ctx, hipMalloc((void**)&m.dev, map.size() * 4));
     HIP_TRY(ctx, hipMemcpy(m.dev, map.data(), map.size() * 4, hipMemcpyHostToDevice));
-    const unsigned regions = ((bx + RT_REGION - 1) / RT_REGION) * ((by + RT_REGION - 1) / RT_REGION);
-    if (reorder && mode == 2 && regions <= (unsigned)ORDER_MAX_REGIONS) {
-        m.nDyn = (regions + 7) / 8 * (8 * RT_REGION * RT_REGION);
+    // a table's region size: the one asked for, doubled until the ordering kernel can hold the regions (0 = it cannot)
+    auto regionsAt = [&](unsigned rs) { return ((bx + rs - 1) / rs) * ((by + rs - 1) / rs); };
+    auto fit = [&](int rs) { while (rs <= 8 && regionsAt((unsigned)rs) > (unsigned)ORDER_MAX_REGIONS) rs *= 2; return rs <= 8 ? rs : 0; };
+    auto entries = [&](int rs) { return (regionsAt((unsigned)rs) + 7) / 8 * (unsigned)(8 * rs * rs); };
+    m.rs = fit(ctx->regionBlocks[0]); m.rsHits = fit(ctx->regionBlocks[1]); m.rsRays = fit(ctx->regionBlocks[2]);
+    m.nDynHits = 0; m.dynRays = nullptr; m.nDynRays = 0;
+    if (reorder && mode == 2 && m.rs && m.rsHits && m.rsRays) {
+        m.nDyn = entries(m.rs);
         HIP_TRY(ctx, hipMalloc((void**)&m.dyn, (size_t)m.nDyn * 4));
         HIP_TRY(ctx, hipMalloc((void**)&m.cost, (size_t)bx * by * 4 * 4));
         HIP_TRY(ctx, hipMemset(m.cost, 0, (size_t)bx * by * 4 * 4));
-        HIP_TRY(ctx, hipMalloc((void**)&m.dynHits, (size_t)m.nDyn * 4));
+        m.nDynHits = entries(m.rsHits);
+        HIP_TRY(ctx, hipMalloc((void**)&m.dynHits, (size_t)m.nDynHits * 4));
+        if (m.rsRays == m.rs) { m.dynRays = m.dyn; m.nDynRays = m.nDyn; }
+        else { m.nDynRays = entries(m.rsRays); HIP_TRY(ctx, hipMalloc((void**)&m.dynRays, (size_t)m.nDynRays * 4)); }
         HIP_TRY(ctx, hipMalloc((void**)&m.steps, (size_t)bx * by * 4 * 4));
         HIP_TRY(ctx, hipMemset(m.steps, 0, (size_t)bx * by * 4 * 4));
     }
     ctx->blockMaps.push_back(m);
     return use(ctx->blockMaps.back());
+}
+void freeBlockMaps(rt_ctx ctx) {
+    hipError_t e = hipSuccess;
+    for (auto& m : ctx->blockMaps) {
+        e = hipFree(m.dev);
+        if (m.dyn) e = hipFree(m.dyn);
+        if (m.cost) e = hipFree(m.cost);
+        if (m.steps) e = hipFree(m.steps);
+        if (m.dynHits) e = hipFree(m.dynHits);
+        if (m.dynRays && m.dynRays != m.dyn) e = hipFree(m.dynRays);
+    }
+    (void)e;
+    ctx->blockMaps.clear();
+}
+// The kernels that cast secondary rays walk a table of their own (smaller regions: see rt_ctx_s::regionBlocks).  Every
+// table of a grid lists the same blocks, so dispatches merged into one launch may have asked for different ones.
+void useRaysTable(const rt_ctx_s::BlockMap* m, KParams& P, unsigned* blocks) {
+    if (m && m->dynValid && m->dynRays) { P.blockMap = m->dynRays; *blocks = m->nDynRays; }
 }
 // After InitialTrace's primary-ray kernel: rank the regions by the hit counts it left and switch this grid to the
 // heaviest-first table (used by every later launch on the same grid, including the next frame's InitialTrace).
@@ -1040,7 +1081,9 @@ void reorderBlocks(rt_ctx ctx, rt_ctx_s::BlockMap* m, bool primaryOnStream1) {
     if (m->dynHits) {
         hipStream_t st = primaryOnStream1 ? ctx->stream1 : SK(ctx);
         traceOrderBlocks(ctx, st, m->cost, m->dynHits);
-        hipLaunchKernelGGL(k_order_blocks, dim3(1), dim3(1024), 0, st, m->cost, m->bx, m->by, m->dynHits, m->nDyn, 0);
+        OrderTables hits = {};
+        hits.t[0].dyn = m->dynHits; hits.t[0].nDyn = m->nDynHits; hits.t[0].rs = m->rsHits;
+        hipLaunchKernelGGL(k_order_blocks, dim3(1), dim3(1024), 0, st, m->cost, m->bx, m->by, hits, 0);
     }
     m->pendingDyn = true;
     m->pendingMeasured = measured;
@@ -1053,8 +1096,12 @@ void reorderBlocksMain(rt_ctx ctx, rt_ctx_s::BlockMap* m) {
     // other stream's next launches behind the new table
     hipStream_t st = SK(ctx);
     joinOthers(ctx);
-    traceOrderBlocks(ctx, st, m->pendingMeasured ? m->steps : m->cost, m->dyn);
-    hipLaunchKernelGGL(k_order_blocks, dim3(1), dim3(1024), 0, st, m->pendingMeasured ? m->steps : m->cost, m->bx, m->by, m->dyn, m->nDyn, m->pendingMeasured ? 1 : 0);
+    traceOrderBlocks(ctx, st, m->pendingMeasured ? m->steps : m->cost, m->dyn, m->dynRays != m->dyn ? m->dynRays : nullptr);
+    OrderTables both = {};
+    both.t[0].dyn = m->dyn; both.t[0].nDyn = m->nDyn; both.t[0].rs = m->rs;
+    both.t[1].dyn = m->dynRays; both.t[1].nDyn = m->nDynRays; both.t[1].rs = m->rsRays;
+    hipLaunchKernelGGL(k_order_blocks, dim3(m->dynRays != m->dyn ? 2 : 1), dim3(1024), 0, st, m->pendingMeasured ? m->steps : m->cost, m->bx, m->by, both,
+                       m->pendingMeasured ? 1 : 0);
     if (!ctx->streamShared && evRecord(ctx, ctx->evTable, st) == hipSuccess) {
         for (int k = 0; k < MAX_FRAMES; k++) {
             if (k == ctx->cur || !ctx->frameStream[k]) continue;
@@ -1306,7 +1353,9 @@ int dispatchReSTIR(rt_shader sh, int kernel, int gx, int gy) {
         instr = true;
     }
     if (rt_buffer wp = boundBuffer(sh, kernel, "WaveProfile")) {  // diagnostics
-        if (wp->stride != 64 || wp->count < (int64_t)blocks * 4 + 64) return fail(ctx, RT_ERR_INVALID_ARG, "WaveProfile needs stride 64 and %u records", blocks * 4 + 64);
+        unsigned most = blocks;   // (the longest of the grid's tables: which one a kernel walks is decided below)
+        if (grid && grid->dynValid) { most = grid->nDynHits > most ? grid->nDynHits : most; most = grid->nDynRays > most ? grid->nDynRays : most; }
+        if (wp->stride != 64 || wp->count < (int64_t)most * 4 + 64) return fail(ctx, RT_ERR_INVALID_ARG, "WaveProfile needs stride 64 and %u records", most * 4 + 64);
         P.waveProfile = (unsigned long long*)wp->dev;
         static const int which = [] { const char* e = getenv("RT_WAVE_PROFILE_KERNEL"); return e ? atoi(e) : 0; }();
         P.waveProfileKernel = which;
@@ -1334,7 +1383,7 @@ int dispatchReSTIR(rt_shader sh, int kernel, int gx, int gy) {
             bool beside = false;
             {
                 if (grid) P.blockCost = grid->cost;
-                if (grid && grid->dynValid && grid->dynHits) { P.blockMap = grid->dynHits; blocks = grid->nDyn; }
+                if (grid && grid->dynValid && grid->dynHits) { P.blockMap = grid->dynHits; blocks = grid->nDynHits; }
                 // beside the kernels stream0 still holds of the frames before, when nothing forbids it (rt_ctx_s::stream1)
                 rt_buffer bHit = boundBuffer(sh, kernel, "HitInfos");
                 rt_texture tDepth = boundTexture(sh, kernel, "DepthBuffer");
@@ -1372,8 +1421,8 @@ int dispatchReSTIR(rt_shader sh, int kernel, int gx, int gy) {
             if (beside && (rc = endOverlappedPrimary(ctx))) return rc;
             reorderBlocksMain(ctx, grid);
             if (grid && grid->dyn) {  // the candidate kernel and everything after it run heaviest regions first
-                P.blockMap = grid->dyn;
-                blocks = grid->nDyn;
+                P.blockMap = grid->dynRays;
+                blocks = grid->nDynRays;
                 P.blockCost = nullptr;
             }
             if (mayHold(ctx, instr)) {  // held: a TemporalReuse that follows becomes part of the launch
@@ -1440,7 +1489,7 @@ int dispatchReSTIR(rt_shader sh, int kernel, int gx, int gy) {
                 // a held candidate kernel over the same buffers, rows, table and constants takes the merge along
                 rt_ctx_s::Deferred& h = ctx->held;
                 const size_t c0 = offsetof(KParams, MaxBVHDepth), c1 = offsetof(KParams, ppFrameCount);
-                if (h.kind == 3 && mayHold(ctx, instr) && h.grid == grid && h.blocks == blocks && h.P.blockMap == P.blockMap && h.P.row0 == P.row0 &&
+                if (h.kind == 3 && mayHold(ctx, instr) && h.grid == grid && h.P.row0 == P.row0 &&
                     h.P.row1 == P.row1 && h.P.cand.q == P.cand.q && h.P.cand.count == P.cand.count && h.P.depth.r == P.depth.r &&
                     memcmp((const char*)&h.P + c0, (const char*)&P + c0, c1 - c0) == 0) {
                     h.P.temporal = P.temporal; h.P.hitA = P.hitA; h.P.hitB = P.hitB;
@@ -1466,11 +1515,12 @@ int dispatchReSTIR(rt_shader sh, int kernel, int gx, int gy) {
             optionalTex(sh, kernel, "EnvironmentMap", P.env);
             if (!blocks) break;
             size_t ldsBytes = (size_t)WAVES_PER_BLOCK * P.stackDepth * 64 * 4;
+            useRaysTable(grid, P, &blocks);
             if (grid && grid->steps) { P.blockSteps = grid->steps; grid->stepsValid = true; }
             if (mayHold(ctx, instr)) {
                 // a held TransferToOriginal over the same buffers, rows and table becomes part of this launch
                 const rt_ctx_s::Deferred& h = ctx->held;
-                const bool takeCopy = h.kind == 1 && h.grid == grid && h.blocks == blocks && h.P.blockMap == P.blockMap && h.P.cand.q == P.cand.q &&
+                const bool takeCopy = h.kind == 1 && h.grid == grid && h.P.cand.q == P.cand.q &&
                                       h.P.cand.count == P.cand.count && h.P.candB.count >= P.cand.count && h.P.row0 == P.row0 && h.P.row1 == P.row1 &&
                                       h.P.ResX == P.ResX && h.P.ResY == P.ResY;
                 if (takeCopy) { P.candB = h.P.candB; P.depth = h.P.depth; ctx->held.kind = 0; }
@@ -1599,6 +1649,7 @@ int dispatchRIS(rt_shader sh, int kernel, int gx, int gy) {
     } else {
         if ((rc = needTex(sh, kernel, "Result", false, X, Y, P.result))) return rc;
         if (!blocks) return RT_OK;
+        useRaysTable(grid, P, &blocks);
         if (cand->epoch != ctx->epoch) joinOthers(ctx);
         if (mayHold(ctx, instr)) {  // held: an AccumulateFrames that follows becomes part of the launch
             SK(ctx);
@@ -1678,7 +1729,7 @@ int dispatchPostProc(rt_shader sh, int kernel, int gx, int gy) {
     {
         // a held TraceRays that writes this Result over the same rows and table takes the running average along
         rt_ctx_s::Deferred& h = ctx->held;
-        if (blocks && (h.kind == 2 || h.kind == 4) && ctx->fuse && !ctx->noAlloc && ctx->statsLevel < 2 && h.grid == grid && h.blocks == blocks && h.P.blockMap == P.blockMap &&
+        if (blocks && (h.kind == 2 || h.kind == 4) && ctx->fuse && !ctx->noAlloc && ctx->statsLevel < 2 && h.grid == grid &&
             h.P.result.rgba == P.result.rgba && h.P.ResX == P.ResX && h.P.ResY == P.ResY && h.P.row0 == P.row0 && h.P.row1 == P.row1) {
             h.P.accumulated = P.accumulated;
             h.P.ppFrameCount = P.ppFrameCount;
@@ -1782,7 +1833,7 @@ void rt_destroy(rt_ctx ctx) {
     if (ctx->bgCounter) e = hipFree(ctx->bgCounter);
     for (rt_shader sh : ctx->shaders) sh->ctx = nullptr;   // a shader closed after its context only frees itself
     if (ctx->noAllocDone) e = hipEventDestroy(ctx->noAllocDone);
-    for (auto& m : ctx->blockMaps) { e = hipFree(m.dev); if (m.dyn) e = hipFree(m.dyn); if (m.cost) e = hipFree(m.cost); if (m.steps) e = hipFree(m.steps); if (m.dynHits) e = hipFree(m.dynHits); }
+    freeBlockMaps(ctx);
     for (auto& t : ctx->pending) { e = hipEventDestroy(t.start); e = hipEventDestroy(t.stop); }
     for (auto ev : ctx->freeEvents) e = hipEventDestroy(ev);
     for (auto ev : ctx->orderEvent) if (ev) e = hipEventDestroy(ev);
@@ -1904,6 +1955,14 @@ int rt_set_tuning(rt_ctx ctx, const char* name, int value) {
     else if (!strcmp(name, "overlap_behind_candidates")) { ctx->behindCandidates = value != 0; ctx->afterCandidatesValid = false; markDirty(ctx); }
     else if (!strcmp(name, "debug_stream_delay_us")) ctx->debugDelayUs = value < 0 ? 0 : value > 2000 ? 2000 : value;
     else if (!strcmp(name, "debug_stream_delay_mask")) ctx->debugDelayMask = value & 0xff;
+    else if (!strcmp(name, "region_blocks_reuse") || !strcmp(name, "region_blocks_primary") || !strcmp(name, "region_blocks_rays")) {
+        if (value != 1 && value != 2 && value != 4 && value != 8) return fail(ctx, RT_ERR_INVALID_ARG, "%s must be 1, 2, 4 or 8", name);
+        // the tables are built when a grid is first used: forget them once nothing can still be reading them
+        useMainStream(ctx);
+        HIP_TRY(ctx, hipStreamSynchronize(S(ctx)));
+        freeBlockMaps(ctx);
+        ctx->regionBlocks[!strcmp(name, "region_blocks_reuse") ? 0 : !strcmp(name, "region_blocks_primary") ? 1 : 2] = value;
+    }
     else if (!strcmp(name, "ris_frames_in_flight")) {
         if (value < 1 || value > MAX_FRAMES) return fail(ctx, RT_ERR_INVALID_ARG, "ris_frames_in_flight must be 1 to %d", MAX_FRAMES);
         useMainStream(ctx);
