@@ -1567,7 +1567,8 @@ struct OrderTables {
 // steps each wave needed for its secondary rays, a region's rank is its longest wave in steps of 8 (the waves with the
 // longest rays must start first: a wave cannot end before its longest ray does).
 __global__ __launch_bounds__(1024) void k_order_blocks(const uint32_t* costW, int BX, int BY, OrderTables out, int byMax) {
-    __shared__ uint32_t hist[66], regionCost[ORDER_MAX_REGIONS];
+    constexpr uint32_t NB = 64;   // ranks (32 cost 1 % of the frame; 128 and 250 gained nothing)
+    __shared__ uint32_t hist[NB + 2], regionCost[ORDER_MAX_REGIONS];
     __shared__ uint16_t order[ORDER_MAX_REGIONS];
     __shared__ uint8_t bucketOf[ORDER_MAX_REGIONS];
     uint32_t* const dyn = out.t[blockIdx.x].dyn;
@@ -1575,7 +1576,7 @@ __global__ __launch_bounds__(1024) void k_order_blocks(const uint32_t* costW, in
     const int RS = out.t[blockIdx.x].rs;
     const int RX = (BX + RS - 1) / RS, RY = (BY + RS - 1) / RS, R = RX * RY;
     const int t = (int)threadIdx.x;
-    if (t < 66) hist[t] = 0;
+    if (t < (int)NB + 2) hist[t] = 0;
     for (int r = t; r < R; r += 1024) regionCost[r] = 0;
     __syncthreads();
     for (int b = t; b < BX * BY; b += 1024) {  // one 16-byte load per block: its four waves' hit counts
@@ -1587,14 +1588,14 @@ __global__ __launch_bounds__(1024) void k_order_blocks(const uint32_t* costW, in
     __syncthreads();
     for (int r = t; r < R; r += 1024) {
         const uint32_t c = byMax ? regionCost[r] * 8 : regionCost[r] * 16 / (RS * RS);  // hit counts: as if the region had 16 blocks
-        const uint32_t step = c / 64 > 64 ? 64 : c / 64;
-        bucketOf[r] = (uint8_t)(64 - step);  // bucket 0 = heaviest
-        atomicAdd(&hist[64 - step], 1u);
+        const uint32_t q = c * NB / 4096, step = q > NB ? NB : q;
+        bucketOf[r] = (uint8_t)(NB - step);  // bucket 0 = heaviest
+        atomicAdd(&hist[NB - step], 1u);
     }
     __syncthreads();
     if (t == 0) {
         uint32_t run = 0;
-        for (int b = 0; b < 65; b++) { const uint32_t n = hist[b]; hist[b] = run; run += n; }
+        for (uint32_t b = 0; b <= NB; b++) { const uint32_t n = hist[b]; hist[b] = run; run += n; }
     }
     __syncthreads();
     for (int r = t; r < R; r += 1024) order[atomicAdd(&hist[bucketOf[r]], 1u)] = (uint16_t)r;
