@@ -1559,18 +1559,24 @@ __global__ void k_recs_merge_tags(Recs rc, OtherCopies others, int64_t first, in
 #ifndef RT_REGION
 #define RT_REGION 4   // blocks per side of a region, where nothing else is asked for
 #endif
-constexpr int ORDER_MAX_REGIONS = 8192;   // (57 KB of LDS in k_order_blocks)
+constexpr int ORDER_MAX_REGIONS = 8192;   // (7 bytes of LDS per region in k_order_blocks: 57 KB)
 struct OrderTables {
     struct { uint32_t* dyn; unsigned nDyn; int rs; } t[2];
 };
 // byMax = 0: costW holds hit pixels per wave, a region's rank is their sum in steps of 64; byMax = 1: costW holds the
 // steps each wave needed for its secondary rays, a region's rank is its longest wave in steps of 8 (the waves with the
 // longest rays must start first: a wave cannot end before its longest ray does).
-__global__ __launch_bounds__(1024) void k_order_blocks(const uint32_t* costW, int BX, int BY, OrderTables out, int byMax) {
+// Dynamic LDS: orderLdsBytes(cap), cap = the most regions any table of the launch has (a workgroup that asks for the
+// full 57 KB waits for a CU with that much free beside the frame's kernels: 36 us per launch instead of 14).
+constexpr size_t orderLdsBytes(unsigned cap) { return (size_t)((cap + 3u) & ~3u) * 7; }
+__global__ __launch_bounds__(1024) void k_order_blocks(const uint32_t* costW, int BX, int BY, OrderTables out, int byMax, unsigned cap) {
     constexpr uint32_t NB = 64;   // ranks (32 cost 1 % of the frame; 128 and 250 gained nothing)
-    __shared__ uint32_t hist[NB + 2], regionCost[ORDER_MAX_REGIONS];
-    __shared__ uint16_t order[ORDER_MAX_REGIONS];
-    __shared__ uint8_t bucketOf[ORDER_MAX_REGIONS];
+    __shared__ uint32_t hist[NB + 2];
+    extern __shared__ uint32_t orderLds[];
+    cap = (cap + 3u) & ~3u;
+    uint32_t* const regionCost = orderLds;
+    uint16_t* const order = (uint16_t*)(orderLds + cap);
+    uint8_t* const bucketOf = (uint8_t*)(order + cap);
     uint32_t* const dyn = out.t[blockIdx.x].dyn;
     const unsigned nDyn = out.t[blockIdx.x].nDyn;
     const int RS = out.t[blockIdx.x].rs;

@@ -994,7 +994,7 @@ int pixelGrid(rt_ctx ctx, KParams& P, int gx, int gy, unsigned* blocks, rt_ctx_s
         m.rs = m.rsHits = m.rsRays = RT_REGION; m.nDynHits = 0; m.dynRays = m.dyn; m.nDynRays = m.nDyn;   // one table for every kernel
         OrderTables one = {};
         one.t[0].dyn = m.dyn; one.t[0].nDyn = m.nDyn; one.t[0].rs = RT_REGION;
-        hipLaunchKernelGGL(k_order_blocks, dim3(1), dim3(1024), 0, S(ctx), m.cost, m.bx, m.by, one, 0);
+        hipLaunchKernelGGL(k_order_blocks, dim3(1), dim3(1024), orderLdsBytes(regions), S(ctx), m.cost, m.bx, m.by, one, 0, regions);
         LAUNCH_TRY(ctx, "order_blocks");
         P.blockMap = m.dev;
         *blocks = m.n;
@@ -1059,6 +1059,9 @@ void freeBlockMaps(rt_ctx ctx) {
     (void)e;
     ctx->blockMaps.clear();
 }
+unsigned regionsOf(const rt_ctx_s::BlockMap* m, int rs) {
+    return (unsigned)((m->bx + rs - 1) / rs) * (unsigned)((m->by + rs - 1) / rs);
+}
 // The kernels that cast secondary rays walk a table of their own (smaller regions: see rt_ctx_s::regionBlocks).  Every
 // table of a grid lists the same blocks, so dispatches merged into one launch may have asked for different ones.
 void useRaysTable(const rt_ctx_s::BlockMap* m, KParams& P, unsigned* blocks) {
@@ -1083,7 +1086,7 @@ void reorderBlocks(rt_ctx ctx, rt_ctx_s::BlockMap* m, bool primaryOnStream1) {
         traceOrderBlocks(ctx, st, m->cost, m->dynHits);
         OrderTables hits = {};
         hits.t[0].dyn = m->dynHits; hits.t[0].nDyn = m->nDynHits; hits.t[0].rs = m->rsHits;
-        hipLaunchKernelGGL(k_order_blocks, dim3(1), dim3(1024), 0, st, m->cost, m->bx, m->by, hits, 0);
+        hipLaunchKernelGGL(k_order_blocks, dim3(1), dim3(1024), orderLdsBytes(regionsOf(m, m->rsHits)), st, m->cost, m->bx, m->by, hits, 0, regionsOf(m, m->rsHits));
     }
     m->pendingDyn = true;
     m->pendingMeasured = measured;
@@ -1100,8 +1103,9 @@ void reorderBlocksMain(rt_ctx ctx, rt_ctx_s::BlockMap* m) {
     OrderTables both = {};
     both.t[0].dyn = m->dyn; both.t[0].nDyn = m->nDyn; both.t[0].rs = m->rs;
     both.t[1].dyn = m->dynRays; both.t[1].nDyn = m->nDynRays; both.t[1].rs = m->rsRays;
-    hipLaunchKernelGGL(k_order_blocks, dim3(m->dynRays != m->dyn ? 2 : 1), dim3(1024), 0, st, m->pendingMeasured ? m->steps : m->cost, m->bx, m->by, both,
-                       m->pendingMeasured ? 1 : 0);
+    const unsigned cap = regionsOf(m, m->rs < m->rsRays ? m->rs : m->rsRays);
+    hipLaunchKernelGGL(k_order_blocks, dim3(m->dynRays != m->dyn ? 2 : 1), dim3(1024), orderLdsBytes(cap), st, m->pendingMeasured ? m->steps : m->cost, m->bx,
+                       m->by, both, m->pendingMeasured ? 1 : 0, cap);
     if (!ctx->streamShared && evRecord(ctx, ctx->evTable, st) == hipSuccess) {
         for (int k = 0; k < MAX_FRAMES; k++) {
             if (k == ctx->cur || !ctx->frameStream[k]) continue;
