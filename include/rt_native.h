@@ -121,6 +121,9 @@ int rt_set_overlap(rt_ctx ctx, int mode);
  *                                 rays.  Doubled while an image has more than 8192 regions of that size.  Setting one waits
  *                                 for the context's work and rebuilds the tables (1080p: 0.697 ms per frame with 4 / 4 / 4,
  *                                 0.686 with 2 for the secondary rays; 4K: 2.436 and 2.407 ms)
+ *   "table_refresh_frames"       (default 8)  the regions are ranked anew every so many InitialTrace dispatches (into a
+ *                                 second pair of tables, so that the frames in flight keep theirs: a refresh that made
+ *                                 the frame wait for the one before cost 0.1 ms, 12 us per frame at 8)
  *   "debug_stream_delay_us"      (default 0) test aid: before about every second launch its stream is held up for a
  *                                 pseudo-random time of up to this many microseconds (at most 2000), so that a missing
  *                                 order between launches of frames in flight shows as a wrong image

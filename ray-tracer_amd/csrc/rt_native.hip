@@ -171,13 +171,18 @@ struct rt_ctx_s {
                       // region sizes (blocks per side) of the three heaviest-first tables, and the tables that differ from `dyn`:
                       // dynHits (ranked by hit pixels: the primary rays) and dynRays (ranked by steps like dyn: the kernels that
                       // cast secondary rays; the same pointer as dyn when the region sizes are equal)
-                      int rs, rsHits, rsRays; unsigned nDynHits; uint32_t* dynRays; unsigned nDynRays; };
+                      int rs, rsHits, rsRays; unsigned nDynHits; uint32_t* dynRays; unsigned nDynRays;
+                      // second buffers for dyn and dynRays: a refresh writes the pair that is not in use and then swaps, so that it
+                      // need not wait for the kernels of the frames in flight that still walk the old tables; swapChange = the
+                      // context's count of copy changes when the spare pair was last in use
+                      uint32_t* dynSpare; uint32_t* dynRaysSpare; uint64_t swapChange; };
     std::vector<BlockMap> blockMaps;  // one per band height in use (a multi-GPU host alternates between a few)
     // Blocks per side of a region in the heaviest-first tables of [0] the reuse, copy and accumulate kernels, [1] the
     // primary rays, [2] the kernels that cast secondary rays (tuning "region_blocks_reuse" / "_primary" / "_rays").
     // Large regions keep an XCD's L2 on one part of the image and of the BVH; small ones let the heaviest-first order
     // balance the XCDs more finely, which is what the secondary rays (few, long, uneven) gain from.
     int regionBlocks[3] = {RT_REGION, RT_REGION, 2};
+    int tableRefreshFrames = 8;   // the tables are ranked anew every so many InitialTrace dispatches (tuning "table_refresh_frames")
     uint32_t* scratch = nullptr;  // this device's address of the file-scope `scratch` array
     bool noAlloc = false;         // set for the duration of rt_dispatch_no_alloc
     BlockMap noAllocMap = {};     // the table of the launch in flight when noAlloc is set (lives in `scratch`)
@@ -992,6 +997,7 @@ int pixelGrid(rt_ctx ctx, KParams& P, int gx, int gy, unsigned* blocks, rt_ctx_s
         HIP_TRY(ctx, hipMemsetAsync(m.cost, 0, (size_t)bx * by * 4 * sizeof(uint32_t), S(ctx)));
         m.steps = nullptr; m.stepsValid = false; m.rankedBySteps = false; m.dynHits = nullptr; m.pendingDyn = false; m.pendingMeasured = false;
         m.rs = m.rsHits = m.rsRays = RT_REGION; m.nDynHits = 0; m.dynRays = m.dyn; m.nDynRays = m.nDyn;   // one table for every kernel
+        m.dynSpare = m.dynRaysSpare = nullptr; m.swapChange = 0;
         OrderTables one = {};
         one.t[0].dyn = m.dyn; one.t[0].nDyn = m.nDyn; one.t[0].rs = RT_REGION;
         hipLaunchKernelGGL(k_order_blocks, dim3(1), dim3(1024), orderLdsBytes(regions), S(ctx), m.cost, m.bx, m.by, one, 0, regions);
@@ -1018,6 +1024,8 @@ int pixelGrid(rt_ctx ctx, KParams& P, int gx, int gy, unsigned* blocks, rt_ctx_s
         if (old.steps) e = hipFree(old.steps);
         if (old.dynHits) e = hipFree(old.dynHits);
         if (old.dynRays && old.dynRays != old.dyn) e = hipFree(old.dynRays);
+        if (old.dynRaysSpare && old.dynRaysSpare != old.dynSpare) e = hipFree(old.dynRaysSpare);
+        if (old.dynSpare) e = hipFree(old.dynSpare);
         (void)e;
         ctx->blockMaps.erase(ctx->blockMaps.begin());
     }
@@ -1030,7 +1038,7 @@ int pixelGrid(rt_ctx ctx, KParams& P, int gx, int gy, unsigned* blocks, rt_ctx_s
     auto fit = [&](int rs) { while (rs <= 8 && regionsAt((unsigned)rs) > (unsigned)ORDER_MAX_REGIONS) rs *= 2; return rs <= 8 ? rs : 0; };
     auto entries = [&](int rs) { return (regionsAt((unsigned)rs) + 7) / 8 * (unsigned)(8 * rs * rs); };
     m.rs = fit(ctx->regionBlocks[0]); m.rsHits = fit(ctx->regionBlocks[1]); m.rsRays = fit(ctx->regionBlocks[2]);
-    m.nDynHits = 0; m.dynRays = nullptr; m.nDynRays = 0;
+    m.nDynHits = 0; m.dynRays = nullptr; m.nDynRays = 0; m.dynSpare = m.dynRaysSpare = nullptr; m.swapChange = 0;
     if (reorder && mode == 2 && m.rs && m.rsHits && m.rsRays) {
         m.nDyn = entries(m.rs);
         HIP_TRY(ctx, hipMalloc((void**)&m.dyn, (size_t)m.nDyn * 4));
@@ -1038,8 +1046,13 @@ int pixelGrid(rt_ctx ctx, KParams& P, int gx, int gy, unsigned* blocks, rt_ctx_s
         HIP_TRY(ctx, hipMemset(m.cost, 0, (size_t)bx * by * 4 * 4));
         m.nDynHits = entries(m.rsHits);
         HIP_TRY(ctx, hipMalloc((void**)&m.dynHits, (size_t)m.nDynHits * 4));
-        if (m.rsRays == m.rs) { m.dynRays = m.dyn; m.nDynRays = m.nDyn; }
-        else { m.nDynRays = entries(m.rsRays); HIP_TRY(ctx, hipMalloc((void**)&m.dynRays, (size_t)m.nDynRays * 4)); }
+        HIP_TRY(ctx, hipMalloc((void**)&m.dynSpare, (size_t)m.nDyn * 4));
+        if (m.rsRays == m.rs) { m.dynRays = m.dyn; m.nDynRays = m.nDyn; m.dynRaysSpare = m.dynSpare; }
+        else {
+            m.nDynRays = entries(m.rsRays);
+            HIP_TRY(ctx, hipMalloc((void**)&m.dynRays, (size_t)m.nDynRays * 4));
+            HIP_TRY(ctx, hipMalloc((void**)&m.dynRaysSpare, (size_t)m.nDynRays * 4));
+        }
         HIP_TRY(ctx, hipMalloc((void**)&m.steps, (size_t)bx * by * 4 * 4));
         HIP_TRY(ctx, hipMemset(m.steps, 0, (size_t)bx * by * 4 * 4));
     }
@@ -1055,6 +1068,8 @@ void freeBlockMaps(rt_ctx ctx) {
         if (m.steps) e = hipFree(m.steps);
         if (m.dynHits) e = hipFree(m.dynHits);
         if (m.dynRays && m.dynRays != m.dyn) e = hipFree(m.dynRays);
+        if (m.dynRaysSpare && m.dynRaysSpare != m.dynSpare) e = hipFree(m.dynRaysSpare);
+        if (m.dynSpare) e = hipFree(m.dynSpare);
     }
     (void)e;
     ctx->blockMaps.clear();
@@ -1078,7 +1093,7 @@ void reorderBlocks(rt_ctx ctx, rt_ctx_s::BlockMap* m, bool primaryOnStream1) {
     // order is still a complete one; it only costs a little balance after a camera cut)
     const bool measured = m->steps && m->stepsValid;
     const bool firstMeasured = measured && !m->rankedBySteps;   // the first frame after measurements exist re-ranks at once
-    if (m->dynValid && !firstMeasured && (++m->age % 8) != 0) return;
+    if (m->dynValid && !firstMeasured && (++m->age % (unsigned)ctx->tableRefreshFrames) != 0) return;
     m->rankedBySteps = measured;
     // the primary rays' cost follows the hit count, not the secondary rays' steps: their launch gets a ranking of its own
     if (m->dynHits) {
@@ -1095,10 +1110,23 @@ void reorderBlocks(rt_ctx ctx, rt_ctx_s::BlockMap* m, bool primaryOnStream1) {
 void reorderBlocksMain(rt_ctx ctx, rt_ctx_s::BlockMap* m) {
     if (!m || !m->dyn || !m->pendingDyn) return;
     m->pendingDyn = false;
-    // kernels of the frame before may still be walking this table on the other frame stream: behind them, and the
-    // other stream's next launches behind the new table
+    // Kernels of the frames before may still be walking the tables on the other frame streams, so the new ones go into
+    // the spare pair, and the other streams' next launches wait for them.  The spare pair was in use until the refresh
+    // before this one: every frame stream is behind what was enqueued MAX_FRAMES changes of copies ago (rt_ctx_s::evBefore),
+    // so after that many changes nothing can still be reading it; otherwise (a refresh right after another, frames that
+    // do not change copies, a table without a spare) this stream first waits for the others.
     hipStream_t st = SK(ctx);
-    joinOthers(ctx);
+    const bool spareFree = m->dynSpare && m->dynValid && !ctx->streamShared && ctx->changes - m->swapChange >= (uint64_t)MAX_FRAMES;
+    if (m->dynSpare && m->dynValid) {
+        if (!spareFree) joinOthers(ctx);
+        const bool oneTable = m->dynRays == m->dyn;
+        std::swap(m->dyn, m->dynSpare);
+        if (oneTable) { m->dynRays = m->dyn; m->dynRaysSpare = m->dynSpare; }
+        else std::swap(m->dynRays, m->dynRaysSpare);
+        m->swapChange = ctx->changes;
+    } else if (m->dynValid) {
+        joinOthers(ctx);
+    }
     traceOrderBlocks(ctx, st, m->pendingMeasured ? m->steps : m->cost, m->dyn, m->dynRays != m->dyn ? m->dynRays : nullptr);
     OrderTables both = {};
     both.t[0].dyn = m->dyn; both.t[0].nDyn = m->nDyn; both.t[0].rs = m->rs;
@@ -1966,6 +1994,10 @@ int rt_set_tuning(rt_ctx ctx, const char* name, int value) {
         HIP_TRY(ctx, hipStreamSynchronize(S(ctx)));
         freeBlockMaps(ctx);
         ctx->regionBlocks[!strcmp(name, "region_blocks_reuse") ? 0 : !strcmp(name, "region_blocks_primary") ? 1 : 2] = value;
+    }
+    else if (!strcmp(name, "table_refresh_frames")) {
+        if (value < 1) return fail(ctx, RT_ERR_INVALID_ARG, "table_refresh_frames must be at least 1");
+        ctx->tableRefreshFrames = value;
     }
     else if (!strcmp(name, "ris_frames_in_flight")) {
         if (value < 1 || value > MAX_FRAMES) return fail(ctx, RT_ERR_INVALID_ARG, "ris_frames_in_flight must be 1 to %d", MAX_FRAMES);

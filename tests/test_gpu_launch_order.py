@@ -26,11 +26,17 @@ def traced(ctx, body):
     return text
 
 
-@pytest.mark.parametrize("in_flight,behind,fuse,weight_recalc", [(2, 1, 1, 0), (3, 1, 1, 0), (4, 1, 1, 0), (2, 0, 1, 0), (3, 0, 1, 1), (2, 1, 0, 0), (1, 0, 1, 0)])
-def test_frames_in_flight_are_ordered(gpu_ctx, scene_small, in_flight, behind, fuse, weight_recalc):
+@pytest.mark.parametrize("in_flight,behind,fuse,weight_recalc,refresh",
+                         [(2, 1, 1, 0, 8), (3, 1, 1, 0, 8), (4, 1, 1, 0, 8), (2, 0, 1, 0, 8), (3, 0, 1, 1, 8), (2, 1, 0, 0, 8), (1, 0, 1, 0, 8),
+                          (4, 1, 1, 0, 4), (4, 0, 1, 0, 5), (3, 1, 1, 0, 3), (2, 1, 1, 0, 1), (4, 1, 1, 0, 2), (4, 0, 1, 0, 1), (3, 1, 1, 0, 1)])
+def test_frames_in_flight_are_ordered(gpu_ctx, scene_small, in_flight, behind, fuse, weight_recalc, refresh):
+    """`refresh`: the heaviest-first workgroup tables are ranked anew every so many frames, into the pair of tables that
+    is not in use - with short periods while frames that walk the old pair are still in flight (the library must then
+    notice that the spare pair may still be read, and wait)."""
     cfg = h.small_config(136, 104)
     cfg.DoWeightRecalc = weight_recalc
     try:
+        gpu_ctx.set_tuning("table_refresh_frames", refresh)
         gpu_ctx.set_tuning("frames_in_flight", in_flight)
         gpu_ctx.set_tuning("overlap_behind_candidates", behind)
         gpu_ctx.set_fusion(bool(fuse))
@@ -54,6 +60,7 @@ def test_frames_in_flight_are_ordered(gpu_ctx, scene_small, in_flight, behind, f
         assert not bad, "\n".join(bad)
         drv.close()
     finally:
+        gpu_ctx.set_tuning("table_refresh_frames", 8)
         gpu_ctx.set_tuning("frames_in_flight", 2)
         gpu_ctx.set_tuning("overlap_behind_candidates", 1)
         gpu_ctx.set_fusion(True)
