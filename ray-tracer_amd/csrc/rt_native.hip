@@ -130,6 +130,7 @@ struct rt_ctx_s {
     // not beside its candidate kernel, which measured a little faster on one GPU (0.745 against 0.756 ms per 1080p frame,
     // 2.43 against 2.47 ms at 3840x2160).
     hipEvent_t evAfterCandidates = nullptr;
+    hipEvent_t afterCandidatesEv = nullptr;   // the event that marks that point now: evAfterCandidates, or one recorded there anyway
     bool afterCandidatesValid = false;
     bool behindCandidates = true;
     bool mainDirty = true;
@@ -211,6 +212,7 @@ struct rt_ctx_s {
         unsigned blocks = 0;
         size_t ldsBytes = 0;
         bool withTransfer = false;
+        bool temporalWaited = false;   // kind 3: the stream already waits for the other frames' TemporalFrameBuffer writes
         BlockMap* grid = nullptr;
     } held;
     bool fuse = true;
@@ -491,8 +493,12 @@ void joinOthers(rt_ctx ctx) {
         if (evRecord(ctx, ctx->evOther[s], ctx->frameStream[s]) == hipSuccess) { hipError_t e = evWait(ctx, mine, ctx->evOther[s]); (void)e; }
     }
 }
-void markAfterCandidates(rt_ctx ctx, hipStream_t stream) {
+// `recordedHere`: an event the caller has just recorded at this very point of the stream (every record is a packet of
+// its own between two kernels: one serves both purposes).
+void markAfterCandidates(rt_ctx ctx, hipStream_t stream, hipEvent_t recordedHere = nullptr) {
     if (!ctx->overlap || !ctx->behindCandidates || !ctx->evAfterCandidates) return;
+    if (recordedHere) { ctx->afterCandidatesEv = recordedHere; ctx->afterCandidatesValid = true; return; }
+    ctx->afterCandidatesEv = ctx->evAfterCandidates;
     ctx->afterCandidatesValid = evRecord(ctx, ctx->evAfterCandidates, stream) == hipSuccess;
 }
 
@@ -1290,7 +1296,7 @@ bool beginOverlappedPrimary(rt_ctx ctx, const Flip* flips, int n, rt_buffer cons
             if (k != next && evWait(ctx, ctx->frameStream[next], ctx->evBefore[old][k]) != hipSuccess) return false;
         }
     }
-    if (ctx->behindCandidates && ctx->afterCandidatesValid && evWait(ctx, ctx->stream1, ctx->evAfterCandidates) != hipSuccess) return false;
+    if (ctx->behindCandidates && ctx->afterCandidatesValid && evWait(ctx, ctx->stream1, ctx->afterCandidatesEv) != hipSuccess) return false;
     ctx->changes = now + 1;
     ctx->cur = next;
     ctx->epoch++;
@@ -1329,14 +1335,14 @@ void launchHeld(rt_ctx ctx, bool acc) {
         LaunchScope ls(ctx, IK_TRANSFER, &h.P, st);
         hipLaunchKernelGGL(k_transfer, dim3(h.blocks), dim3(256), 0, st, h.P);
     } else if (h.kind == 3) {
-        if (acc) waitShared(ctx, rt_ctx_s::SH_TEMPORAL, st);
+        if (acc && !h.temporalWaited) waitShared(ctx, rt_ctx_s::SH_TEMPORAL, st);
         {
             LaunchScope ls(ctx, IK_CANDIDATES, &h.P, st, acc);
             if (acc) hipLaunchKernelGGL((k_candidates<false, true>), dim3(h.blocks), dim3(256), h.ldsBytes, st, h.P);
             else hipLaunchKernelGGL((k_candidates<false, false>), dim3(h.blocks), dim3(256), h.ldsBytes, st, h.P);
         }
         if (acc) markShared(ctx, rt_ctx_s::SH_TEMPORAL, st);
-        markAfterCandidates(ctx, st);
+        markAfterCandidates(ctx, st, acc && ctx->sharedValid[rt_ctx_s::SH_TEMPORAL][ctx->cur] ? ctx->evShared[rt_ctx_s::SH_TEMPORAL][ctx->cur] : nullptr);
     } else if (h.kind == 4) {
         waitShared(ctx, rt_ctx_s::SH_RESULT, st);
         {
@@ -1450,6 +1456,11 @@ int dispatchReSTIR(rt_shader sh, int kernel, int gx, int gy) {
                 if (!beside) markDirty(ctx);   // primary rays on stream0: the next overlapped ones follow them
             }
             if (grid && grid->dyn) reorderBlocks(ctx, grid, beside);   // (the primary rays' own table: behind them, on their stream)
+            // A TemporalReuse merged into the candidate kernel makes it wait for the frames before.  That wait has long
+            // been met when the primary rays end, but the stream works its waits off in order, and each costs a few
+            // microseconds: it goes ahead of the wait for the primary rays, the one the kernel really stands still for.
+            const bool temporalEarly = beside && mayHold(ctx, instr);
+            if (temporalEarly) waitShared(ctx, rt_ctx_s::SH_TEMPORAL, frameStreamNow(ctx));
             if (beside && (rc = endOverlappedPrimary(ctx))) return rc;
             reorderBlocksMain(ctx, grid);
             if (grid && grid->dyn) {  // the candidate kernel and everything after it run heaviest regions first
@@ -1460,7 +1471,7 @@ int dispatchReSTIR(rt_shader sh, int kernel, int gx, int gy) {
             if (mayHold(ctx, instr)) {  // held: a TemporalReuse that follows becomes part of the launch
                 SK(ctx);
                 ctx->held.kind = 3; ctx->held.P = P; ctx->held.blocks = blocks; ctx->held.ldsBytes = ldsBytes; ctx->held.grid = grid;
-                ctx->held.withTransfer = false;
+                ctx->held.withTransfer = false; ctx->held.temporalWaited = temporalEarly;
             } else {
                 hipStream_t st = SK(ctx);
                 {
