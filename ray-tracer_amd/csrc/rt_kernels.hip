@@ -215,11 +215,15 @@ DEV v3 matCol(const KParams& P, const rt_material& m, v2 uv) {
 // from a table built on the host (rt_native.hip: buildBlockMap), which orders blocks so that the workgroups that
 // land on one XCD (launch index mod 8, the observed round-robin placement; used for speed only) render compact
 // image regions, and the regions are dealt evenly to the XCDs.
+// A launch may also give every wave a workgroup of its own (64 threads, four times the workgroups): workgroup i then
+// renders tile (i / 8) mod 4 of table entry (i / 32) * 8 + i mod 8, so that a block's four tiles stay on one XCD.
 struct Pixel { int x, y; bool active; };
+DEV uint32_t waveInBlock() { return blockDim.x == 64 ? (blockIdx.x >> 3) & 3u : threadIdx.x >> 6; }
+DEV uint32_t tableEntryOfGroup() { return blockDim.x == 64 ? ((blockIdx.x >> 5) << 3) | (blockIdx.x & 7u) : blockIdx.x; }
 DEV Pixel pixelOfThread(const KParams& P, uint32_t launchBlock) {
     const uint32_t m = P.blockMap[launchBlock];
     const uint32_t bx = m & 0xffffu, by = m >> 16;
-    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const uint32_t wave = waveInBlock(), lane = threadIdx.x & 63;
     Pixel p;
     p.x = (int)(bx * 16 + (wave & 1) * 8 + (lane & 7));
     p.y = (P.row0 & ~7) + (int)(by * 16 + (wave >> 1) * 8 + (lane >> 3));
@@ -228,24 +232,24 @@ DEV Pixel pixelOfThread(const KParams& P, uint32_t launchBlock) {
 }
 
 // Cost estimate of this wave's tile for the launches that follow the primary-ray kernel: its number of hit pixels.
-DEV Pixel pixelOfThread(const KParams& P) { return pixelOfThread(P, blockIdx.x); }
+DEV Pixel pixelOfThread(const KParams& P) { return pixelOfThread(P, tableEntryOfGroup()); }
 DEV void writeTileCost(const KParams& P, bool hit, uint32_t launchBlock) {
     if (!P.blockCost) return;
     const unsigned long long hitMask = __builtin_amdgcn_ballot_w64(hit);
     const uint32_t m = P.blockMap[launchBlock];
     if ((threadIdx.x & 63) == 0 && m != 0xffffffffu)
-        P.blockCost[((size_t)(m >> 16) * P.blocksX + (m & 0xffffu)) * 4 + (threadIdx.x >> 6)] = (uint32_t)__builtin_popcountll(hitMask);
+        P.blockCost[((size_t)(m >> 16) * P.blocksX + (m & 0xffffu)) * 4 + waveInBlock()] = (uint32_t)__builtin_popcountll(hitMask);
 }
 
 // Measured cost of this wave's tile: the steps the wave needed for its secondary rays (0 in lanes that cast none).  The
 // regions of the image are ranked by it for the launches of the following frames (k_order_blocks).
-DEV void writeTileCost(const KParams& P, bool hit) { writeTileCost(P, hit, blockIdx.x); }
+DEV void writeTileCost(const KParams& P, bool hit) { writeTileCost(P, hit, tableEntryOfGroup()); }
 DEV void writeTileSteps(const KParams& P, uint32_t steps) {
     if (!P.blockSteps) return;
     for (int off = 32; off > 0; off >>= 1) { const uint32_t o = __shfl_xor(steps, off, 64); steps = o > steps ? o : steps; }
-    const uint32_t m = P.blockMap[blockIdx.x];
+    const uint32_t m = P.blockMap[tableEntryOfGroup()];
     if ((threadIdx.x & 63) == 0 && m != 0xffffffffu)
-        P.blockSteps[((size_t)(m >> 16) * P.blocksX + (m & 0xffffu)) * 4 + (threadIdx.x >> 6)] = steps;
+        P.blockSteps[((size_t)(m >> 16) * P.blocksX + (m & 0xffffu)) * 4 + waveInBlock()] = steps;
 }
 
 // ---------------- BVH traversal ----------------
@@ -840,7 +844,7 @@ template <bool INSTR, bool BG = false>
 __global__ __launch_bounds__(256, RT_PRIMARY_WAVES) void k_primary(const KParams P) {
     extern __shared__ uint32_t lds[];
     if (!BG) {
-        primaryBlock<INSTR>(P, blockIdx.x, lds);
+        primaryBlock<INSTR>(P, tableEntryOfGroup(), lds);
         return;
     }
     __shared__ uint32_t nextEntry;

@@ -183,6 +183,10 @@ struct rt_ctx_s {
     // Large regions keep an XCD's L2 on one part of the image and of the BVH; small ones let the heaviest-first order
     // balance the XCDs more finely, which is what the secondary rays (few, long, uneven) gain from.
     int regionBlocks[3] = {RT_REGION, RT_REGION, 2};
+    // Traversal kernels launched with one wave per workgroup (tuning "one_wave_groups", RT_WG64): bit 0 the kernels that
+    // cast secondary rays, bit 1 the ReSTIR project's primary rays, bit 2 the RIS project's.  A wave's slot and LDS are
+    // free for the next workgroup as soon as that wave ends - what counts when kernels of several frames share the chip.
+    int oneWaveGroups = [] { const char* e = getenv("RT_WG64"); return e ? atoi(e) & 7 : 5; }();
     int tableRefreshFrames = 8;   // the tables are ranked anew every so many InitialTrace dispatches (tuning "table_refresh_frames")
     uint32_t* scratch = nullptr;  // this device's address of the file-scope `scratch` array
     bool noAlloc = false;         // set for the duration of rt_dispatch_no_alloc
@@ -1321,6 +1325,15 @@ bool mayOverlap(rt_ctx ctx, bool instr, const KParams& P) {
     return wholeImage || ctx->overlap == 2;
 }
 
+// Launch geometry of the traversal kernels: by choice (rt_ctx_s::oneWaveGroups) one wave per workgroup - four times the
+// workgroups, a quarter of the LDS each - instead of the four waves of a 16x16-pixel block.  `kind`: 0 secondary rays,
+// 1 the ReSTIR project's primary rays, 2 the RIS project's.  The table has to come in rounds of eight entries (every
+// table but the plain row-major one does).
+enum { RAYS_SECONDARY = 0, RAYS_PRIMARY = 1, RAYS_RIS_PRIMARY = 2 };
+bool oneWaveGroups(rt_ctx ctx, unsigned blocks, int kind) { return ((ctx->oneWaveGroups >> kind) & 1) && blocks % 8 == 0; }
+dim3 rayGrid(rt_ctx ctx, unsigned blocks, int kind = RAYS_SECONDARY) { return dim3(oneWaveGroups(ctx, blocks, kind) ? blocks * 4 : blocks); }
+dim3 rayBlock(rt_ctx ctx, unsigned blocks, int kind = RAYS_SECONDARY) { return dim3(oneWaveGroups(ctx, blocks, kind) ? 64 : 256); }
+size_t rayLds(rt_ctx ctx, unsigned blocks, size_t ldsBytes, int kind = RAYS_SECONDARY) { return oneWaveGroups(ctx, blocks, kind) ? ldsBytes / 4 : ldsBytes; }
 // Launches what is held back (rt_ctx_s::Deferred), as it was dispatched.  `acc` = the dispatch that follows is merged into
 // it (AccumulateFrames into a held TraceRays, TemporalReuse into a held candidate kernel): the caller has put what that
 // dispatch binds into the held parameters.
@@ -1338,8 +1351,8 @@ void launchHeld(rt_ctx ctx, bool acc) {
         if (acc && !h.temporalWaited) waitShared(ctx, rt_ctx_s::SH_TEMPORAL, st);
         {
             LaunchScope ls(ctx, IK_CANDIDATES, &h.P, st, acc);
-            if (acc) hipLaunchKernelGGL((k_candidates<false, true>), dim3(h.blocks), dim3(256), h.ldsBytes, st, h.P);
-            else hipLaunchKernelGGL((k_candidates<false, false>), dim3(h.blocks), dim3(256), h.ldsBytes, st, h.P);
+            if (acc) hipLaunchKernelGGL((k_candidates<false, true>), rayGrid(ctx, h.blocks), rayBlock(ctx, h.blocks), rayLds(ctx, h.blocks, h.ldsBytes), st, h.P);
+            else hipLaunchKernelGGL((k_candidates<false, false>), rayGrid(ctx, h.blocks), rayBlock(ctx, h.blocks), rayLds(ctx, h.blocks, h.ldsBytes), st, h.P);
         }
         if (acc) markShared(ctx, rt_ctx_s::SH_TEMPORAL, st);
         markAfterCandidates(ctx, st, acc && ctx->sharedValid[rt_ctx_s::SH_TEMPORAL][ctx->cur] ? ctx->evShared[rt_ctx_s::SH_TEMPORAL][ctx->cur] : nullptr);
@@ -1347,8 +1360,8 @@ void launchHeld(rt_ctx ctx, bool acc) {
         waitShared(ctx, rt_ctx_s::SH_RESULT, st);
         {
             LaunchScope ls(ctx, IK_RIS_TRACE_RAYS, &h.P, st, false, acc);
-            if (acc) hipLaunchKernelGGL((k_ris_trace_rays<false, true>), dim3(h.blocks), dim3(256), h.ldsBytes, st, h.P);
-            else hipLaunchKernelGGL((k_ris_trace_rays<false, false>), dim3(h.blocks), dim3(256), h.ldsBytes, st, h.P);
+            if (acc) hipLaunchKernelGGL((k_ris_trace_rays<false, true>), rayGrid(ctx, h.blocks), rayBlock(ctx, h.blocks), rayLds(ctx, h.blocks, h.ldsBytes), st, h.P);
+            else hipLaunchKernelGGL((k_ris_trace_rays<false, false>), rayGrid(ctx, h.blocks), rayBlock(ctx, h.blocks), rayLds(ctx, h.blocks, h.ldsBytes), st, h.P);
         }
         markShared(ctx, rt_ctx_s::SH_RESULT, st);
     } else if (h.kind == 2) {
@@ -1356,10 +1369,10 @@ void launchHeld(rt_ctx ctx, bool acc) {
         if (h.P.kwWeightRecalc) waitShared(ctx, rt_ctx_s::SH_TEMPORAL, st);   // (RS:645-657 writes into TemporalFrameBuffer)
         {
             LaunchScope ls(ctx, IK_TRACE_RAYS, &h.P, st, h.withTransfer, acc);
-            if (h.withTransfer && acc) hipLaunchKernelGGL((k_trace_rays<false, true, true>), dim3(h.blocks), dim3(256), h.ldsBytes, st, h.P);
-            else if (h.withTransfer) hipLaunchKernelGGL((k_trace_rays<false, true, false>), dim3(h.blocks), dim3(256), h.ldsBytes, st, h.P);
-            else if (acc) hipLaunchKernelGGL((k_trace_rays<false, false, true>), dim3(h.blocks), dim3(256), h.ldsBytes, st, h.P);
-            else hipLaunchKernelGGL((k_trace_rays<false, false, false>), dim3(h.blocks), dim3(256), h.ldsBytes, st, h.P);
+            if (h.withTransfer && acc) hipLaunchKernelGGL((k_trace_rays<false, true, true>), rayGrid(ctx, h.blocks), rayBlock(ctx, h.blocks), rayLds(ctx, h.blocks, h.ldsBytes), st, h.P);
+            else if (h.withTransfer) hipLaunchKernelGGL((k_trace_rays<false, true, false>), rayGrid(ctx, h.blocks), rayBlock(ctx, h.blocks), rayLds(ctx, h.blocks, h.ldsBytes), st, h.P);
+            else if (acc) hipLaunchKernelGGL((k_trace_rays<false, false, true>), rayGrid(ctx, h.blocks), rayBlock(ctx, h.blocks), rayLds(ctx, h.blocks, h.ldsBytes), st, h.P);
+            else hipLaunchKernelGGL((k_trace_rays<false, false, false>), rayGrid(ctx, h.blocks), rayBlock(ctx, h.blocks), rayLds(ctx, h.blocks, h.ldsBytes), st, h.P);
         }
         markShared(ctx, rt_ctx_s::SH_RESULT, st);
         if (h.P.kwWeightRecalc) markShared(ctx, rt_ctx_s::SH_TEMPORAL, st);
@@ -1451,7 +1464,7 @@ int dispatchReSTIR(rt_shader sh, int kernel, int gx, int gy) {
                         P.bgCounter = ctx->bgCounter; P.bgBlocks = blocks;
                         hipLaunchKernelGGL((k_primary<false, true>), dim3((unsigned)ctx->bgGroups), dim3(256), ldsBytes, ls.stream, P);
                     } else if (instr) hipLaunchKernelGGL(k_primary<true>, dim3(blocks), dim3(256), ldsBytes, ls.stream, P);
-                    else hipLaunchKernelGGL(k_primary<false>, dim3(blocks), dim3(256), ldsBytes, ls.stream, P);
+                    else hipLaunchKernelGGL((k_primary<false>), rayGrid(ctx, blocks, RAYS_PRIMARY), rayBlock(ctx, blocks, RAYS_PRIMARY), rayLds(ctx, blocks, ldsBytes, RAYS_PRIMARY), ls.stream, P);
                 }
                 if (!beside) markDirty(ctx);   // primary rays on stream0: the next overlapped ones follow them
             }
@@ -1477,7 +1490,7 @@ int dispatchReSTIR(rt_shader sh, int kernel, int gx, int gy) {
                 {
                     LaunchScope ls(ctx, IK_CANDIDATES, &P, st);
                     if (instr) hipLaunchKernelGGL((k_candidates<true>), dim3(blocks), dim3(256), ldsBytes, st, P);
-                    else hipLaunchKernelGGL((k_candidates<false>), dim3(blocks), dim3(256), ldsBytes, st, P);
+                    else hipLaunchKernelGGL((k_candidates<false>), rayGrid(ctx, blocks), rayBlock(ctx, blocks), rayLds(ctx, blocks, ldsBytes), st, P);
                 }
                 markAfterCandidates(ctx, st);
             }
@@ -1577,7 +1590,7 @@ int dispatchReSTIR(rt_shader sh, int kernel, int gx, int gy) {
                 {
                     LaunchScope ls(ctx, IK_TRACE_RAYS, &P, st);
                     if (instr) hipLaunchKernelGGL((k_trace_rays<true>), dim3(blocks), dim3(256), ldsBytes, st, P);
-                    else hipLaunchKernelGGL((k_trace_rays<false>), dim3(blocks), dim3(256), ldsBytes, st, P);
+                    else hipLaunchKernelGGL((k_trace_rays<false>), rayGrid(ctx, blocks), rayBlock(ctx, blocks), rayLds(ctx, blocks, ldsBytes), st, P);
                 }
                 markShared(ctx, rt_ctx_s::SH_RESULT, st);
                 if (P.kwWeightRecalc) markShared(ctx, rt_ctx_s::SH_TEMPORAL, st);
@@ -1670,7 +1683,7 @@ int dispatchRIS(rt_shader sh, int kernel, int gx, int gy) {
             {
                 LaunchScope ls(ctx, IK_RIS_PRIMARY, &P, beside ? ctx->stream1 : nullptr);
                 if (instr) hipLaunchKernelGGL(k_ris_primary<true>, dim3(blocks), dim3(256), ldsBytes, ls.stream, P);
-                else hipLaunchKernelGGL(k_ris_primary<false>, dim3(blocks), dim3(256), ldsBytes, ls.stream, P);
+                else hipLaunchKernelGGL((k_ris_primary<false>), rayGrid(ctx, blocks, RAYS_RIS_PRIMARY), rayBlock(ctx, blocks, RAYS_RIS_PRIMARY), rayLds(ctx, blocks, ldsBytes, RAYS_RIS_PRIMARY), ls.stream, P);
             }
             if (!beside) markDirty(ctx);   // primary rays on stream0: the next overlapped ones follow them
         }
@@ -1704,7 +1717,7 @@ int dispatchRIS(rt_shader sh, int kernel, int gx, int gy) {
             {
                 LaunchScope ls(ctx, IK_RIS_TRACE_RAYS, &P, st);
                 if (instr) hipLaunchKernelGGL((k_ris_trace_rays<true>), dim3(blocks), dim3(256), ldsBytes, st, P);
-                else hipLaunchKernelGGL((k_ris_trace_rays<false>), dim3(blocks), dim3(256), ldsBytes, st, P);
+                else hipLaunchKernelGGL((k_ris_trace_rays<false>), rayGrid(ctx, blocks), rayBlock(ctx, blocks), rayLds(ctx, blocks, ldsBytes), st, P);
             }
             markShared(ctx, rt_ctx_s::SH_RESULT, st);
         }
@@ -2005,6 +2018,10 @@ int rt_set_tuning(rt_ctx ctx, const char* name, int value) {
         HIP_TRY(ctx, hipStreamSynchronize(S(ctx)));
         freeBlockMaps(ctx);
         ctx->regionBlocks[!strcmp(name, "region_blocks_reuse") ? 0 : !strcmp(name, "region_blocks_primary") ? 1 : 2] = value;
+    }
+    else if (!strcmp(name, "one_wave_groups")) {
+        if (value < 0 || value > 7) return fail(ctx, RT_ERR_INVALID_ARG, "one_wave_groups is a mask of bits 0 to 2");
+        ctx->oneWaveGroups = value;
     }
     else if (!strcmp(name, "table_refresh_frames")) {
         if (value < 1) return fail(ctx, RT_ERR_INVALID_ARG, "table_refresh_frames must be at least 1");
