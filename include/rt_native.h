@@ -121,10 +121,12 @@ int rt_set_overlap(rt_ctx ctx, int mode);
  *                                 rays.  Doubled while an image has more than 8192 regions of that size.  Setting one waits
  *                                 for the context's work and rebuilds the tables (1080p: 0.697 ms per frame with 4 / 4 / 4,
  *                                 0.686 with 2 for the secondary rays; 4K: 2.436 and 2.407 ms)
- *   "one_wave_groups"            (RT_WG64, default 5)  traversal kernels launched with one wave per workgroup instead of
- *                                 the four of a 16x16-pixel block: bit 0 the kernels that cast secondary rays, bit 1 the
- *                                 ReSTIR project's primary rays, bit 2 the RIS project's (1080p ReSTIR frame 0.675 ms with
- *                                 0, 0.669 with 1, 0.683 with 3; RIS frame 0.587 / 0.567 / 0.554 ms with 0 / 1 / 5)
+ *   "one_wave_groups"            (RT_WG64, default 15)  per-pixel kernels launched with one wave per workgroup instead
+ *                                 of the four of a 16x16-pixel block: bit 0 the kernels that cast secondary rays, bit 1 the
+ *                                 ReSTIR project's primary rays, bit 2 the RIS project's, bit 3 SpatialReusePass, bit 4 the
+ *                                 RIS project's candidate kernel (1080p ReSTIR frame 0.675 ms with 0, 0.664 with 5, 0.683
+ *                                 with 7, 0.656 with 15; 4K 2.43 / 2.35 ms with 5 / 15; RIS frame 0.587 / 0.552 / 0.569 ms
+ *                                 with 0 / 5 / 21)
  *   "table_refresh_frames"       (default 8)  the regions are ranked anew every so many InitialTrace dispatches (into a
  *                                 second pair of tables, so that the frames in flight keep theirs: a refresh that made
  *                                 the frame wait for the one before cost 0.1 ms, 12 us per frame at 8)

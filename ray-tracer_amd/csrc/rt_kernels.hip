@@ -1044,8 +1044,9 @@ __global__ __launch_bounds__(256) void k_temporal(const KParams P) {
 // =====================================================================================================
 // SpatialReusePass (RS:514-571)
 // =====================================================================================================
+// Dynamic LDS: 64 * COOP_ROW float4 per wave of the workgroup (four waves, or one: see waveInBlock).
 __global__ __launch_bounds__(256) void k_spatial(const KParams P) {
-    __shared__ float4 stageAll[WAVES_PER_BLOCK * 64 * COOP_ROW];
+    extern __shared__ float4 stageAll[];
     float4* stage = stageAll + (threadIdx.x >> 6) * 64 * COOP_ROW;
     const Pixel px = pixelOfThread(P);
     bool active = px.active;

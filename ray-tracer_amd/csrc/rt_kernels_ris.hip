@@ -172,12 +172,13 @@ DEV int risTriReservoirSample(const KParams& P, int startTriIndex, int endTriInd
 // wave stages 8 candidates per pixel in LDS and then writes them out 8 lanes per pixel: whole 128-byte runs.
 constexpr int RIS_STAGE = 8;                   // candidates staged per pixel
 constexpr int RIS_STAGE_ROW = RIS_STAGE + 1;   // float4s per staged pixel (one of padding: spreads the LDS banks)
+// Dynamic LDS: risStageBytes per wave of the workgroup (four waves, or one: see waveInBlock).
+constexpr size_t risStageBytes = 64 * RIS_STAGE_ROW * sizeof(float4) + 64 * sizeof(int);
 __global__ __launch_bounds__(256) void k_ris_candidates(const KParams P) {
-    __shared__ float4 stageAll[WAVES_PER_BLOCK * 64 * RIS_STAGE_ROW];
-    __shared__ int baseAll[WAVES_PER_BLOCK * 64];
-    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    extern __shared__ float4 stageAll[];
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6, waves = blockDim.x >> 6;
     float4* stage = stageAll + wave * 64 * RIS_STAGE_ROW;
-    int* rowBase = baseAll + wave * 64;
+    int* rowBase = (int*)(stageAll + waves * 64 * RIS_STAGE_ROW) + wave * 64;
     const Pixel px = pixelOfThread(P);
     uint32_t generated = 0;
     const uint32_t idx = (uint32_t)px.x, idy = (uint32_t)px.y;

@@ -183,10 +183,12 @@ struct rt_ctx_s {
     // Large regions keep an XCD's L2 on one part of the image and of the BVH; small ones let the heaviest-first order
     // balance the XCDs more finely, which is what the secondary rays (few, long, uneven) gain from.
     int regionBlocks[3] = {RT_REGION, RT_REGION, 2};
-    // Traversal kernels launched with one wave per workgroup (tuning "one_wave_groups", RT_WG64): bit 0 the kernels that
-    // cast secondary rays, bit 1 the ReSTIR project's primary rays, bit 2 the RIS project's.  A wave's slot and LDS are
-    // free for the next workgroup as soon as that wave ends - what counts when kernels of several frames share the chip.
-    int oneWaveGroups = [] { const char* e = getenv("RT_WG64"); return e ? atoi(e) & 7 : 5; }();
+    // Per-pixel kernels launched with one wave per workgroup (tuning "one_wave_groups", RT_WG64): bit 0 the kernels that
+    // cast secondary rays, bit 1 the ReSTIR project's primary rays, bit 2 the RIS project's, bit 3 SpatialReusePass,
+    // bit 4 the RIS project's candidate kernel.  A wave's slot and LDS are free for the next workgroup as soon as that
+    // wave ends - what counts when kernels of several frames share the chip; and kernels that run beside one another
+    // should ask for slots in the same unit (primary rays in single waves beside reuse passes in fours starve the passes).
+    int oneWaveGroups = [] { const char* e = getenv("RT_WG64"); return e ? atoi(e) & 31 : 15; }();
     int tableRefreshFrames = 8;   // the tables are ranked anew every so many InitialTrace dispatches (tuning "table_refresh_frames")
     uint32_t* scratch = nullptr;  // this device's address of the file-scope `scratch` array
     bool noAlloc = false;         // set for the duration of rt_dispatch_no_alloc
@@ -1325,11 +1327,11 @@ bool mayOverlap(rt_ctx ctx, bool instr, const KParams& P) {
     return wholeImage || ctx->overlap == 2;
 }
 
-// Launch geometry of the traversal kernels: by choice (rt_ctx_s::oneWaveGroups) one wave per workgroup - four times the
-// workgroups, a quarter of the LDS each - instead of the four waves of a 16x16-pixel block.  `kind`: 0 secondary rays,
-// 1 the ReSTIR project's primary rays, 2 the RIS project's.  The table has to come in rounds of eight entries (every
-// table but the plain row-major one does).
-enum { RAYS_SECONDARY = 0, RAYS_PRIMARY = 1, RAYS_RIS_PRIMARY = 2 };
+// Launch geometry of the per-pixel kernels that share nothing between the waves of a block: by choice
+// (rt_ctx_s::oneWaveGroups) one wave per workgroup - four times the workgroups, a quarter of the LDS each - instead of
+// the four waves of a 16x16-pixel block.  `kind` = the bit of that choice.  The table has to come in rounds of eight
+// entries (every table but the plain row-major one does).
+enum { RAYS_SECONDARY = 0, RAYS_PRIMARY = 1, RAYS_RIS_PRIMARY = 2, RAYS_REUSE = 3, RAYS_RIS_CANDIDATES = 4 };
 bool oneWaveGroups(rt_ctx ctx, unsigned blocks, int kind) { return ((ctx->oneWaveGroups >> kind) & 1) && blocks % 8 == 0; }
 dim3 rayGrid(rt_ctx ctx, unsigned blocks, int kind = RAYS_SECONDARY) { return dim3(oneWaveGroups(ctx, blocks, kind) ? blocks * 4 : blocks); }
 dim3 rayBlock(rt_ctx ctx, unsigned blocks, int kind = RAYS_SECONDARY) { return dim3(oneWaveGroups(ctx, blocks, kind) ? 64 : 256); }
@@ -1516,7 +1518,8 @@ int dispatchReSTIR(rt_shader sh, int kernel, int gx, int gy) {
                 }
                 LaunchScope ls(ctx, IK_SPATIAL, &P);
                 if (staged) hipLaunchKernelGGL(k_spatial_lds, dim3(blocks), dim3(256), ldsBytes, ls.stream, P);
-                else hipLaunchKernelGGL(k_spatial, dim3(blocks), dim3(256), 0, ls.stream, P);
+                else hipLaunchKernelGGL(k_spatial, rayGrid(ctx, blocks, RAYS_REUSE), rayBlock(ctx, blocks, RAYS_REUSE),
+                                        rayLds(ctx, blocks, (size_t)WAVES_PER_BLOCK * 64 * COOP_ROW * sizeof(float4), RAYS_REUSE), ls.stream, P);
             }
             break;
         }
@@ -1698,7 +1701,8 @@ int dispatchRIS(rt_shader sh, int kernel, int gx, int gy) {
         if (cand->epoch != ctx->epoch) joinOthers(ctx);   // Candidates without a copy for this frame: behind the frame before
         {
             LaunchScope ls(ctx, IK_RIS_CANDIDATES, &P);
-            hipLaunchKernelGGL(k_ris_candidates, dim3(blocks), dim3(256), 0, ls.stream, P);
+            hipLaunchKernelGGL(k_ris_candidates, rayGrid(ctx, blocks, RAYS_RIS_CANDIDATES), rayBlock(ctx, blocks, RAYS_RIS_CANDIDATES),
+                               rayLds(ctx, blocks, WAVES_PER_BLOCK * risStageBytes, RAYS_RIS_CANDIDATES), ls.stream, P);
             // (no markAfterCandidates: the RIS project's primary rays do best beside the whole of the frame before,
             // 0.756 against 0.784 ms per 1080p frame)
         }
@@ -2020,7 +2024,7 @@ int rt_set_tuning(rt_ctx ctx, const char* name, int value) {
         ctx->regionBlocks[!strcmp(name, "region_blocks_reuse") ? 0 : !strcmp(name, "region_blocks_primary") ? 1 : 2] = value;
     }
     else if (!strcmp(name, "one_wave_groups")) {
-        if (value < 0 || value > 7) return fail(ctx, RT_ERR_INVALID_ARG, "one_wave_groups is a mask of bits 0 to 2");
+        if (value < 0 || value > 31) return fail(ctx, RT_ERR_INVALID_ARG, "one_wave_groups is a mask of bits 0 to 4");
         ctx->oneWaveGroups = value;
     }
     else if (!strcmp(name, "table_refresh_frames")) {

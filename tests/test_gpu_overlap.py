@@ -189,13 +189,13 @@ def test_banded_dispatches_of_one_frame_do_not_flip(gpu_ctx, scene_small):
 
 @pytest.mark.parametrize("name,value", [("spatial_lds_max_offset", 3), ("spatial_lds_max_offset", 1), ("primary_background_groups", 64),
                                         ("overlap_behind_candidates", 0), ("region_blocks_rays", 1), ("region_blocks_rays", 4),
-                                        ("region_blocks_reuse", 2), ("region_blocks_primary", 8), ("one_wave_groups", 0), ("one_wave_groups", 7)])
+                                        ("region_blocks_reuse", 2), ("region_blocks_primary", 8), ("one_wave_groups", 0), ("one_wave_groups", 5), ("one_wave_groups", 31)])
 def test_speed_only_choices_leave_every_bit_alone(gpu_ctx, scene_small, name, value):
     """rt_set_tuning: the alternatives that were measured and not adopted still render the same frames - the LDS-staged
     SpatialReusePass (also with a window of +-1, and with blocks at x < MaxOffset whose neighbours wrap into the row
     above), primary rays as a background launch, primary rays started as early as their inputs allow, other region
     sizes for the three heaviest-first workgroup tables (the dispatches merged into one launch then ask for different
-    tables of the same grid), traversal kernels with four waves or one wave per workgroup."""
+    tables of the same grid), per-pixel kernels with four waves or one wave per workgroup."""
     cfg = h.small_config(488, 264)   # 31 x 17 blocks, ragged on both edges
     cfg.SpatialReuseBlur = 1 if (name, value) == ("spatial_lds_max_offset", 1) else 3
     try:
@@ -218,7 +218,7 @@ def test_speed_only_choices_leave_every_bit_alone(gpu_ctx, scene_small, name, va
             gpu_ctx.set_tuning("region_blocks_rays", 3)
     finally:
         for n, v in (("spatial_lds_max_offset", 0), ("primary_background_groups", 0), ("overlap_behind_candidates", 1),
-                     ("region_blocks_rays", 2), ("region_blocks_reuse", 4), ("region_blocks_primary", 4), ("one_wave_groups", 5)):
+                     ("region_blocks_rays", 2), ("region_blocks_reuse", 4), ("region_blocks_primary", 4), ("one_wave_groups", 15)):
             gpu_ctx.set_tuning(n, v)
 
 

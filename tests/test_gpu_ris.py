@@ -16,10 +16,14 @@ def _compare_frame(drv, orc, what=""):
         assert np.array_equal(h.bits(drv.texture(name)), h.bits(orc.tex[name])), (what, name)
 
 
-@pytest.mark.parametrize("res,tri_cand,obj_cand,tests", [((64, 64), 4, 1, 3), ((72, 40), 1, 1, 1), ((40, 56), 3, 2, 0)])
-def test_frames_match_oracle(gpu_ctx, scene_small, res, tri_cand, obj_cand, tests):
+@pytest.mark.parametrize("res,tri_cand,obj_cand,tests,one_wave", [((64, 64), 4, 1, 3, None), ((72, 40), 1, 1, 1, None), ((40, 56), 3, 2, 0, None),
+                                                                  ((72, 56), 9, 2, 2, 0), ((72, 56), 9, 2, 2, 31)])
+def test_frames_match_oracle(gpu_ctx, scene_small, res, tri_cand, obj_cand, tests, one_wave):
+    """`one_wave`: every kernel with four waves per workgroup (0) or one (31) instead of the default mix."""
     cfg = h.small_ris_config(*res, tri_candidates=tri_cand, tests=tests)
     cfg.SceneObjectCandidatesNum = obj_cand
+    if one_wave is not None:
+        gpu_ctx.set_tuning("one_wave_groups", one_wave)
     drv = rt.RisDriver(gpu_ctx, cfg, scene_small)
     try:
         orc = h.RisOracleRenderer(scene_small.arrays(), cfg)
@@ -38,6 +42,7 @@ def test_frames_match_oracle(gpu_ctx, scene_small, res, tri_cand, obj_cand, test
             assert (orc.tex["Result"][..., :3] > 0).any()
     finally:
         drv.close()
+        gpu_ctx.set_tuning("one_wave_groups", 15)
 
 
 def test_trace_records_and_counters(gpu_ctx, scene_small):
