@@ -1560,21 +1560,24 @@ __global__ void k_recs_merge_tags(Recs rc, OtherCopies others, int64_t first, in
 // Regions (RS x RS blocks; 64x64 pixels at RS = 4) are ranked by their hit pixels in steps of 64 (a counting sort; the
 // order inside a step is whatever the atomics give: any permutation renders the same image) and dealt to the 8 XCDs in
 // that order; every XCD still walks whole regions.  One workgroup per table: workgroup b writes `out.t[b]`, which has
-// ceil(regions / 8) * 8 * RS * RS entries, from the same counts.
+// ceil(regions / 8) * 8 * RS * RS entries, from that table's counts.
 #ifndef RT_REGION
 #define RT_REGION 4   // blocks per side of a region, where nothing else is asked for
 #endif
 constexpr int ORDER_MAX_REGIONS = 8192;   // (7 bytes of LDS per region in k_order_blocks: 57 KB)
 struct OrderTables {
-    struct { uint32_t* dyn; unsigned nDyn; int rs; } t[2];
+    struct { uint32_t* dyn; unsigned nDyn; int rs; const uint32_t* costW; int byMax; } t[3];
 };
-// byMax = 0: costW holds hit pixels per wave, a region's rank is their sum in steps of 64; byMax = 1: costW holds the
+// Per table - byMax = 0: costW holds hit pixels per wave, a region's rank is their sum in steps of 64; byMax = 1: costW holds the
 // steps each wave needed for its secondary rays, a region's rank is its longest wave in steps of 8 (the waves with the
 // longest rays must start first: a wave cannot end before its longest ray does).
 // Dynamic LDS: orderLdsBytes(cap), cap = the most regions any table of the launch has (a workgroup that asks for the
 // full 57 KB waits for a CU with that much free beside the frame's kernels: 36 us per launch instead of 14).
 constexpr size_t orderLdsBytes(unsigned cap) { return (size_t)((cap + 3u) & ~3u) * 7; }
-__global__ __launch_bounds__(1024) void k_order_blocks(const uint32_t* costW, int BX, int BY, OrderTables out, int byMax, unsigned cap) {
+constexpr int ORDER_THREADS = 1024;   // (256 or 64 threads are no sooner done beside the frame's kernels: 71 and 90 us against 62)
+__global__ __launch_bounds__(ORDER_THREADS) void k_order_blocks(int BX, int BY, OrderTables out, unsigned cap) {
+    const uint32_t* const costW = out.t[blockIdx.x].costW;
+    const int byMax = out.t[blockIdx.x].byMax;
     constexpr uint32_t NB = 64;   // ranks (32 cost 1 % of the frame; 128 and 250 gained nothing)
     __shared__ uint32_t hist[NB + 2];
     extern __shared__ uint32_t orderLds[];
@@ -1588,16 +1591,16 @@ __global__ __launch_bounds__(1024) void k_order_blocks(const uint32_t* costW, in
     const int RX = (BX + RS - 1) / RS, RY = (BY + RS - 1) / RS, R = RX * RY;
     const int t = (int)threadIdx.x;
     if (t < (int)NB + 2) hist[t] = 0;
-    for (int r = t; r < R; r += 1024) regionCost[r] = 0;
+    for (int r = t; r < R; r += ORDER_THREADS) regionCost[r] = 0;
     __syncthreads();
-    for (int b = t; b < BX * BY; b += 1024) {  // one 16-byte load per block: its four waves' hit counts
+    for (int b = t; b < BX * BY; b += ORDER_THREADS) {  // one 16-byte load per block: its four waves' hit counts
         const uint4 w = ((const uint4*)costW)[b];
         uint32_t* rc = &regionCost[(b / BX / RS) * RX + (b % BX) / RS];
         if (byMax) atomicMax(rc, max(max(w.x, w.y), max(w.z, w.w)));
         else atomicAdd(rc, w.x + w.y + w.z + w.w);
     }
     __syncthreads();
-    for (int r = t; r < R; r += 1024) {
+    for (int r = t; r < R; r += ORDER_THREADS) {
         const uint32_t c = byMax ? regionCost[r] * 8 : regionCost[r] * 16 / (RS * RS);  // hit counts: as if the region had 16 blocks
         const uint32_t q = c * NB / 4096, step = q > NB ? NB : q;
         bucketOf[r] = (uint8_t)(NB - step);  // bucket 0 = heaviest
@@ -1609,9 +1612,9 @@ __global__ __launch_bounds__(1024) void k_order_blocks(const uint32_t* costW, in
         for (uint32_t b = 0; b <= NB; b++) { const uint32_t n = hist[b]; hist[b] = run; run += n; }
     }
     __syncthreads();
-    for (int r = t; r < R; r += 1024) order[atomicAdd(&hist[bucketOf[r]], 1u)] = (uint16_t)r;
+    for (int r = t; r < R; r += ORDER_THREADS) order[atomicAdd(&hist[bucketOf[r]], 1u)] = (uint16_t)r;
     __syncthreads();
-    for (unsigned m = (unsigned)t; m < nDyn; m += 1024) {
+    for (unsigned m = (unsigned)t; m < nDyn; m += ORDER_THREADS) {
         const unsigned xcd = m % 8, j = m / 8, ord = (j / (RS * RS)) * 8 + xcd, k = j % (RS * RS);
         uint32_t entry = 0xffffffffu;
         if ((int)ord < R) {

@@ -113,6 +113,8 @@ struct rt_ctx_s {
     bool ahead[MAX_FRAMES] = {};     // [s >= 1] frameStream[s] holds work stream0 has not been made to wait for
     bool dirty[MAX_FRAMES] = {};     // [s >= 1] stream0 holds work frameStream[s] has not been made to wait for
     hipEvent_t evJoin[MAX_FRAMES] = {}, evOther[MAX_FRAMES] = {}, evTail0 = nullptr, evTable = nullptr;
+    hipEvent_t evTableAside = nullptr;   // behind a table refresh on stream1 (refreshTables)
+    bool asidePending = false;           // ... that no frame stream has been made to wait for yet
     enum { SH_TEMPORAL = 0, SH_RESULT = 1, SH_COUNT = 2 };
     hipEvent_t evShared[SH_COUNT][MAX_FRAMES] = {};
     bool sharedValid[SH_COUNT][MAX_FRAMES] = {};
@@ -176,7 +178,8 @@ struct rt_ctx_s {
                       // second buffers for dyn and dynRays: a refresh writes the pair that is not in use and then swaps, so that it
                       // need not wait for the kernels of the frames in flight that still walk the old tables; swapChange = the
                       // context's count of copy changes when the spare pair was last in use
-                      uint32_t* dynSpare; uint32_t* dynRaysSpare; uint64_t swapChange; };
+                      uint32_t* dynSpare; uint32_t* dynRaysSpare; uint64_t swapChange;
+                      bool pendingSwap; };   // the spare pair holds tables built aside that the next InitialTrace takes up
     std::vector<BlockMap> blockMaps;  // one per band height in use (a multi-GPU host alternates between a few)
     // Blocks per side of a region in the heaviest-first tables of [0] the reuse, copy and accumulate kernels, [1] the
     // primary rays, [2] the kernels that cast secondary rays (tuning "region_blocks_reuse" / "_primary" / "_rays").
@@ -394,12 +397,16 @@ void traceLaunch(rt_ctx ctx, hipStream_t stream, int ik, const KParams* Pp, bool
     }
     ctx->traceOps.push_back(t.op);
 }
-void traceOrderBlocks(rt_ctx ctx, hipStream_t stream, const void* counts, const void* table, const void* table2 = nullptr) {
+void traceOrderBlocks(rt_ctx ctx, hipStream_t stream, const void* counts, const void* table, const void* table2 = nullptr,
+                      const void* counts2 = nullptr, const void* table3 = nullptr, const void* table4 = nullptr) {
     if (!ctx->tracing) return;
     TraceLaunch t(ctx, stream, "order_blocks");
     t.add(counts, false, true);
+    if (counts2 && counts2 != counts) t.add(counts2, false, true);
     t.w(table);
     if (table2) t.w(table2);
+    if (table3) t.w(table3);
+    if (table4) t.w(table4);
     ctx->traceOps.push_back(t.op);
 }
 
@@ -446,6 +453,8 @@ hipStream_t frameStreamNow(rt_ctx ctx) {
 }
 // stream0 behind everything the other frame streams hold.
 void collapse(rt_ctx ctx) {
+    // (stream1: the primary rays are covered by the frame streams, which wait for them; a table refresh behind them is not)
+    if (ctx->asidePending && evWait(ctx, ctx->stream0, ctx->evTableAside) == hipSuccess) ctx->asidePending = false;
     for (int s = 1; s < MAX_FRAMES; s++) {
         if (!ctx->ahead[s]) continue;
         if (evRecord(ctx, ctx->evJoin[s], ctx->frameStream[s]) == hipSuccess && evWait(ctx, ctx->stream0, ctx->evJoin[s]) == hipSuccess) ctx->ahead[s] = false;
@@ -1009,10 +1018,10 @@ int pixelGrid(rt_ctx ctx, KParams& P, int gx, int gy, unsigned* blocks, rt_ctx_s
         HIP_TRY(ctx, hipMemsetAsync(m.cost, 0, (size_t)bx * by * 4 * sizeof(uint32_t), S(ctx)));
         m.steps = nullptr; m.stepsValid = false; m.rankedBySteps = false; m.dynHits = nullptr; m.pendingDyn = false; m.pendingMeasured = false;
         m.rs = m.rsHits = m.rsRays = RT_REGION; m.nDynHits = 0; m.dynRays = m.dyn; m.nDynRays = m.nDyn;   // one table for every kernel
-        m.dynSpare = m.dynRaysSpare = nullptr; m.swapChange = 0;
+        m.dynSpare = m.dynRaysSpare = nullptr; m.swapChange = 0; m.pendingSwap = false;
         OrderTables one = {};
-        one.t[0].dyn = m.dyn; one.t[0].nDyn = m.nDyn; one.t[0].rs = RT_REGION;
-        hipLaunchKernelGGL(k_order_blocks, dim3(1), dim3(1024), orderLdsBytes(regions), S(ctx), m.cost, m.bx, m.by, one, 0, regions);
+        one.t[0].dyn = m.dyn; one.t[0].nDyn = m.nDyn; one.t[0].rs = RT_REGION; one.t[0].costW = m.cost; one.t[0].byMax = 0;
+        hipLaunchKernelGGL(k_order_blocks, dim3(1), dim3(ORDER_THREADS), orderLdsBytes(regions), S(ctx), m.bx, m.by, one, regions);
         LAUNCH_TRY(ctx, "order_blocks");
         P.blockMap = m.dev;
         *blocks = m.n;
@@ -1050,7 +1059,7 @@ int pixelGrid(rt_ctx ctx, KParams& P, int gx, int gy, unsigned* blocks, rt_ctx_s
     auto fit = [&](int rs) { while (rs <= 8 && regionsAt((unsigned)rs) > (unsigned)ORDER_MAX_REGIONS) rs *= 2; return rs <= 8 ? rs : 0; };
     auto entries = [&](int rs) { return (regionsAt((unsigned)rs) + 7) / 8 * (unsigned)(8 * rs * rs); };
     m.rs = fit(ctx->regionBlocks[0]); m.rsHits = fit(ctx->regionBlocks[1]); m.rsRays = fit(ctx->regionBlocks[2]);
-    m.nDynHits = 0; m.dynRays = nullptr; m.nDynRays = 0; m.dynSpare = m.dynRaysSpare = nullptr; m.swapChange = 0;
+    m.nDynHits = 0; m.dynRays = nullptr; m.nDynRays = 0; m.dynSpare = m.dynRaysSpare = nullptr; m.swapChange = 0; m.pendingSwap = false;
     if (reorder && mode == 2 && m.rs && m.rsHits && m.rsRays) {
         m.nDyn = entries(m.rs);
         HIP_TRY(ctx, hipMalloc((void**)&m.dyn, (size_t)m.nDyn * 4));
@@ -1086,6 +1095,27 @@ void freeBlockMaps(rt_ctx ctx) {
     (void)e;
     ctx->blockMaps.clear();
 }
+void swapTables(rt_ctx_s::BlockMap* m) {
+    const bool oneTable = m->dynRays == m->dyn;
+    std::swap(m->dyn, m->dynSpare);
+    if (oneTable) { m->dynRays = m->dyn; m->dynRaysSpare = m->dynSpare; }
+    else std::swap(m->dynRays, m->dynRaysSpare);
+}
+// The tables a refresh built aside (refreshTables) come into use: from here on dispatches walk them, and every frame
+// stream first waits for the launch that wrote them (long done: it ran a frame ago).  `done`: that has been waited for.
+void applyTableSwap(rt_ctx ctx, rt_ctx_s::BlockMap* m, bool done = false) {
+    if (!m || !m->pendingSwap) { if (m && done) { swapTables(m); m->swapChange = ctx->changes; } return; }
+    m->pendingSwap = false;
+    swapTables(m);
+    m->swapChange = ctx->changes;
+    if (done) return;
+    for (int k = 0; k < MAX_FRAMES; k++) {
+        if (!ctx->frameStream[k]) continue;
+        hipError_t e = evWait(ctx, ctx->frameStream[k], ctx->evTableAside);
+        (void)e;
+    }
+    ctx->asidePending = false;   // (stream0 is among them)
+}
 unsigned regionsOf(const rt_ctx_s::BlockMap* m, int rs) {
     return (unsigned)((m->bx + rs - 1) / rs) * (unsigned)((m->by + rs - 1) / rs);
 }
@@ -1094,58 +1124,70 @@ unsigned regionsOf(const rt_ctx_s::BlockMap* m, int rs) {
 void useRaysTable(const rt_ctx_s::BlockMap* m, KParams& P, unsigned* blocks) {
     if (m && m->dynValid && m->dynRays) { P.blockMap = m->dynRays; *blocks = m->nDynRays; }
 }
-// After InitialTrace's primary-ray kernel: rank the regions by the hit counts it left and switch this grid to the
-// heaviest-first table (used by every later launch on the same grid, including the next frame's InitialTrace).
-// `primaryOnStream1`: the primary rays that left the hit counts run on stream1, and so will the next ones: their own
-// table (dynHits) is rebuilt there, behind the launch that counted and ahead of the next one that reads it, and the
-// table of stream0's kernels on stream0, where it is called from once stream0 waits for the primary rays.
-void reorderBlocks(rt_ctx ctx, rt_ctx_s::BlockMap* m, bool primaryOnStream1) {
+// Ranks the regions anew and rebuilds the grid's heaviest-first tables (used by every later launch on the same grid).
+// Called from the InitialTrace / GenerateCandidates dispatch once the primary rays are on their stream and the frame's
+// stream has been told to wait for them.  The ranking moves slowly from frame to frame: it is refreshed on the first
+// frame, on the first frame after TraceRays has measured its steps, and then every `tableRefreshFrames`-th dispatch (a
+// stale order is still a complete one; it only costs a little balance after a camera cut).
+//
+// Beside the frames in flight (`beside`: the primary rays run on stream1): all three tables are rebuilt by ONE launch on
+// stream1, behind the primary rays that counted the hits and ahead of the next ones - a stream that stands idle until
+// the next frame's primary rays start, so the 60 us this single workgroup takes on a busy chip delay nobody.  The
+// primary rays' table is rewritten in place (only stream1 reads it).  The step-ranked tables are written into the spare
+// pair and come into use at the next such dispatch (applyTableSwap), so that neither this frame nor the frames in flight
+// wait: the spare pair was in use until the swap before; every frame stream and stream1 are behind everything
+// dispatched MAX_FRAMES changes of copies ago (rt_ctx_s::evBefore), so after that many changes nothing can still be
+// reading it.  Otherwise - the very first tables, refreshes close together, frames that change no copies, a table
+// without a spare, one stream for everything - the frame's stream rebuilds its tables itself, behind the other frames.
+void launchOrderBlocks(rt_ctx ctx, hipStream_t st, const rt_ctx_s::BlockMap* m, const OrderTables& tables, int n) {
+    unsigned cap = 0;
+    for (int i = 0; i < n; i++) { const unsigned r = regionsOf(m, tables.t[i].rs); cap = r > cap ? r : cap; }
+    hipLaunchKernelGGL(k_order_blocks, dim3((unsigned)n), dim3(ORDER_THREADS), orderLdsBytes(cap), st, m->bx, m->by, tables, cap);
+}
+void refreshTables(rt_ctx ctx, rt_ctx_s::BlockMap* m, bool beside) {
     if (!m || !m->dyn) return;
-    // the ranking moves slowly from frame to frame: refresh it on the first frame and then every eighth (a stale
-    // order is still a complete one; it only costs a little balance after a camera cut)
     const bool measured = m->steps && m->stepsValid;
     const bool firstMeasured = measured && !m->rankedBySteps;   // the first frame after measurements exist re-ranks at once
     if (m->dynValid && !firstMeasured && (++m->age % (unsigned)ctx->tableRefreshFrames) != 0) return;
     m->rankedBySteps = measured;
-    // the primary rays' cost follows the hit count, not the secondary rays' steps: their launch gets a ranking of its own
-    if (m->dynHits) {
-        hipStream_t st = primaryOnStream1 ? ctx->stream1 : SK(ctx);
+    const uint32_t* const counts = measured ? m->steps : m->cost;
+    const int byMax = measured ? 1 : 0;
+    const bool oneTable = m->dynRays == m->dyn;
+    OrderTables t = {};
+    int n = 0;
+    // the primary rays' cost follows the hit count, not the secondary rays' steps: their launch has a ranking of its own
+    if (m->dynHits) { t.t[n].dyn = m->dynHits; t.t[n].nDyn = m->nDynHits; t.t[n].rs = m->rsHits; t.t[n].costW = m->cost; t.t[n].byMax = 0; n++; }
+    const bool aside = beside && m->dynHits && m->dynSpare && m->dynValid && !m->pendingSwap && !ctx->streamShared &&
+                       ctx->changes - m->swapChange >= (uint64_t)MAX_FRAMES;
+    if (aside) {
+        t.t[n].dyn = m->dynSpare; t.t[n].nDyn = m->nDyn; t.t[n].rs = m->rs; t.t[n].costW = counts; t.t[n].byMax = byMax; n++;
+        if (!oneTable) { t.t[n].dyn = m->dynRaysSpare; t.t[n].nDyn = m->nDynRays; t.t[n].rs = m->rsRays; t.t[n].costW = counts; t.t[n].byMax = byMax; n++; }
+        traceOrderBlocks(ctx, ctx->stream1, m->cost, m->dynHits, nullptr, counts, m->dynSpare, oneTable ? nullptr : m->dynRaysSpare);
+        launchOrderBlocks(ctx, ctx->stream1, m, t, n);
+        m->pendingSwap = evRecord(ctx, ctx->evTableAside, ctx->stream1) == hipSuccess;
+        ctx->asidePending = m->pendingSwap;
+        if (!m->pendingSwap) { hipError_t e = hipStreamSynchronize(ctx->stream1); (void)e; applyTableSwap(ctx, m, true); }   // (cannot order it: wait here)
+        return;
+    }
+    if (m->pendingSwap) applyTableSwap(ctx, m);   // (a refresh right after another: first take up what the last one built)
+    if (n) {
+        hipStream_t st = beside ? ctx->stream1 : SK(ctx);
         traceOrderBlocks(ctx, st, m->cost, m->dynHits);
-        OrderTables hits = {};
-        hits.t[0].dyn = m->dynHits; hits.t[0].nDyn = m->nDynHits; hits.t[0].rs = m->rsHits;
-        hipLaunchKernelGGL(k_order_blocks, dim3(1), dim3(1024), orderLdsBytes(regionsOf(m, m->rsHits)), st, m->cost, m->bx, m->by, hits, 0, regionsOf(m, m->rsHits));
+        launchOrderBlocks(ctx, st, m, t, n);
+        if (beside) ctx->asidePending = evRecord(ctx, ctx->evTableAside, st) == hipSuccess || ctx->asidePending;
     }
-    m->pendingDyn = true;
-    m->pendingMeasured = measured;
-}
-// The second half, on stream0 after it has been made to wait for the primary rays.
-void reorderBlocksMain(rt_ctx ctx, rt_ctx_s::BlockMap* m) {
-    if (!m || !m->dyn || !m->pendingDyn) return;
-    m->pendingDyn = false;
-    // Kernels of the frames before may still be walking the tables on the other frame streams, so the new ones go into
-    // the spare pair, and the other streams' next launches wait for them.  The spare pair was in use until the refresh
-    // before this one: every frame stream is behind what was enqueued MAX_FRAMES changes of copies ago (rt_ctx_s::evBefore),
-    // so after that many changes nothing can still be reading it; otherwise (a refresh right after another, frames that
-    // do not change copies, a table without a spare) this stream first waits for the others.
+    // The frame's stream, which waits for the primary rays: behind the kernels of the frames before that may still be
+    // walking the tables on the other frame streams, whose next launches wait for the new tables in turn.
     hipStream_t st = SK(ctx);
-    const bool spareFree = m->dynSpare && m->dynValid && !ctx->streamShared && ctx->changes - m->swapChange >= (uint64_t)MAX_FRAMES;
-    if (m->dynSpare && m->dynValid) {
-        if (!spareFree) joinOthers(ctx);
-        const bool oneTable = m->dynRays == m->dyn;
-        std::swap(m->dyn, m->dynSpare);
-        if (oneTable) { m->dynRays = m->dyn; m->dynRaysSpare = m->dynSpare; }
-        else std::swap(m->dynRays, m->dynRaysSpare);
-        m->swapChange = ctx->changes;
-    } else if (m->dynValid) {
+    if (m->dynValid) {
         joinOthers(ctx);
+        if (m->dynSpare) { swapTables(m); m->swapChange = ctx->changes; }
     }
-    traceOrderBlocks(ctx, st, m->pendingMeasured ? m->steps : m->cost, m->dyn, m->dynRays != m->dyn ? m->dynRays : nullptr);
-    OrderTables both = {};
-    both.t[0].dyn = m->dyn; both.t[0].nDyn = m->nDyn; both.t[0].rs = m->rs;
-    both.t[1].dyn = m->dynRays; both.t[1].nDyn = m->nDynRays; both.t[1].rs = m->rsRays;
-    const unsigned cap = regionsOf(m, m->rs < m->rsRays ? m->rs : m->rsRays);
-    hipLaunchKernelGGL(k_order_blocks, dim3(m->dynRays != m->dyn ? 2 : 1), dim3(1024), orderLdsBytes(cap), st, m->pendingMeasured ? m->steps : m->cost, m->bx,
-                       m->by, both, m->pendingMeasured ? 1 : 0, cap);
+    OrderTables u = {};
+    u.t[0].dyn = m->dyn; u.t[0].nDyn = m->nDyn; u.t[0].rs = m->rs; u.t[0].costW = counts; u.t[0].byMax = byMax;
+    u.t[1].dyn = m->dynRays; u.t[1].nDyn = m->nDynRays; u.t[1].rs = m->rsRays; u.t[1].costW = counts; u.t[1].byMax = byMax;
+    traceOrderBlocks(ctx, st, counts, m->dyn, oneTable ? nullptr : m->dynRays);
+    launchOrderBlocks(ctx, st, m, u, oneTable ? 1 : 2);
     if (!ctx->streamShared && evRecord(ctx, ctx->evTable, st) == hipSuccess) {
         for (int k = 0; k < MAX_FRAMES; k++) {
             if (k == ctx->cur || !ctx->frameStream[k]) continue;
@@ -1442,6 +1484,7 @@ int dispatchReSTIR(rt_shader sh, int kernel, int gx, int gy) {
                 rt_texture tDepth = boundTexture(sh, kernel, "DepthBuffer");
                 rt_texture tPoints = boundTexture(sh, kernel, P.FrameCount % 2 == 0 ? "RayHitPointsA" : "RayHitPointsB");
                 SK(ctx);   // (what is held goes first: it was dispatched before this)
+                applyTableSwap(ctx, grid);   // tables the last refresh built aside: from this frame on
                 const Flip flips[3] = {{&bHit->dev, &bHit->more, layoutBytes(bHit, bHit->layout)}, {&tDepth->dev, &tDepth->more, tDepth->bytes},
                                        {&tPoints->dev, &tPoints->more, tPoints->bytes}};
                 // the reservoirs this frame's kernels write: Candidates, and the CandidatesB that SpatialReusePass is bound to
@@ -1470,14 +1513,13 @@ int dispatchReSTIR(rt_shader sh, int kernel, int gx, int gy) {
                 }
                 if (!beside) markDirty(ctx);   // primary rays on stream0: the next overlapped ones follow them
             }
-            if (grid && grid->dyn) reorderBlocks(ctx, grid, beside);   // (the primary rays' own table: behind them, on their stream)
             // A TemporalReuse merged into the candidate kernel makes it wait for the frames before.  That wait has long
             // been met when the primary rays end, but the stream works its waits off in order, and each costs a few
             // microseconds: it goes ahead of the wait for the primary rays, the one the kernel really stands still for.
             const bool temporalEarly = beside && mayHold(ctx, instr);
             if (temporalEarly) waitShared(ctx, rt_ctx_s::SH_TEMPORAL, frameStreamNow(ctx));
             if (beside && (rc = endOverlappedPrimary(ctx))) return rc;
-            reorderBlocksMain(ctx, grid);
+            refreshTables(ctx, grid, beside);
             if (grid && grid->dyn) {  // the candidate kernel and everything after it run heaviest regions first
                 P.blockMap = grid->dynRays;
                 blocks = grid->nDynRays;
@@ -1669,6 +1711,7 @@ int dispatchRIS(rt_shader sh, int kernel, int gx, int gy) {
             // per frame in flight (tagged per pixel ray, like the reservoir records) GenerateCandidates of the next frame
             // runs beside TraceRays of this one; only Result is shared
             SK(ctx);
+            applyTableSwap(ctx, grid);   // tables the last refresh built aside: from this frame on
             const int group = P.TotCandidatesNum > 0 ? P.TotCandidatesNum : 1;
             if (cand->tag && cand->tagGroup != group) {   // another number of candidates per ray: the tags no longer fit
                 mergeRecords(cand);
@@ -1690,9 +1733,8 @@ int dispatchRIS(rt_shader sh, int kernel, int gx, int gy) {
             }
             if (!beside) markDirty(ctx);   // primary rays on stream0: the next overlapped ones follow them
         }
-        if (grid && grid->dyn) reorderBlocks(ctx, grid, beside);
         if (beside && (rc = endOverlappedPrimary(ctx))) return rc;
-        reorderBlocksMain(ctx, grid);
+        refreshTables(ctx, grid, beside);
         if (grid && grid->dyn) {
             P.blockMap = grid->dyn;
             blocks = grid->nDyn;
@@ -1854,7 +1896,7 @@ int rt_create(int device_id, rt_ctx* out) {
         // (the third and fourth dispatch stream are made when they are asked for: a process has few hardware queues -
         // four by default - and streams that share one run one after the other)
         for (int k = 1; k < ctx->framesInFlight; k++) ok = ok && hipStreamCreateWithFlags(&ctx->frameStream[k], hipStreamNonBlocking) == hipSuccess;
-        std::vector<hipEvent_t*> evs = {&ctx->evAfterCandidates, &ctx->evPrimary, &ctx->evTail0, &ctx->evTable};
+        std::vector<hipEvent_t*> evs = {&ctx->evAfterCandidates, &ctx->evPrimary, &ctx->evTail0, &ctx->evTable, &ctx->evTableAside};
         for (auto& ev : ctx->evJoin) evs.push_back(&ev);
         for (auto& ev : ctx->evOther) evs.push_back(&ev);
         for (auto& per : ctx->evShared) for (auto& ev : per) evs.push_back(&ev);
@@ -1901,7 +1943,7 @@ void rt_destroy(rt_ctx ctx) {
     if (ctx->transferStream) { e = hipStreamSynchronize(ctx->transferStream); e = hipStreamDestroy(ctx->transferStream); }
     if (ctx->stream1) { e = hipStreamSynchronize(ctx->stream1); e = hipStreamDestroy(ctx->stream1); }
     for (int k = 1; k < MAX_FRAMES; k++) if (ctx->frameStream[k]) { e = hipStreamSynchronize(ctx->frameStream[k]); e = hipStreamDestroy(ctx->frameStream[k]); }
-    for (hipEvent_t ev : {ctx->evPrimary, ctx->evAfterCandidates, ctx->evTail0, ctx->evTable}) if (ev) e = hipEventDestroy(ev);
+    for (hipEvent_t ev : {ctx->evPrimary, ctx->evAfterCandidates, ctx->evTail0, ctx->evTable, ctx->evTableAside}) if (ev) e = hipEventDestroy(ev);
     for (hipEvent_t ev : ctx->evJoin) if (ev) e = hipEventDestroy(ev);
     for (hipEvent_t ev : ctx->evOther) if (ev) e = hipEventDestroy(ev);
     for (auto& per : ctx->evShared) for (hipEvent_t ev : per) if (ev) e = hipEventDestroy(ev);
