@@ -182,8 +182,10 @@ def test_stamps_and_row_reports_check_their_arguments(gpu_ctx):
         gpu_ctx.check(lib.rt_buffer_rows_written(buf, 8, 0, 8), "rt_buffer_rows_written")   # a buffer with one copy: nothing to do
     finally:
         lib.rt_buffer_release(buf)
-    with pytest.raises(rt.NativeError):
-        gpu_ctx.set_tuning("frames_in_flight", 5)
+    for name, bad in (("frames_in_flight", 5), ("one_wave_groups", 32), ("one_wave_groups", -1), ("table_refresh_frames", 0),
+                      ("region_blocks_rays", 3), ("region_blocks_primary", 16), ("region_blocks_reuse", 0)):
+        with pytest.raises(rt.NativeError):
+            gpu_ctx.set_tuning(name, bad)
     gpu_ctx.sync()
 
 
