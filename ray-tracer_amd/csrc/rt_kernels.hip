@@ -772,8 +772,8 @@ DEV v2 GetLastUV(const KParams& P, v3 worldFocalPos) {  // RS:451-461
 // InitialTrace, first half (RS:463-491,496-509): camera ray, closest hit, G-buffer outputs.
 // =====================================================================================================
 #ifndef RT_PRIMARY_WAVES
-#define RT_PRIMARY_WAVES 5
-#endif
+#define RT_PRIMARY_WAVES 4   // 101 registers, nothing spilled.  (5 = 96 registers with 5 values spilled was the better choice while the
+#endif                     // kernel ran in workgroups of four waves; in single waves 4 gives 157 against 166 us, 6 gives 190.)
 // The work of one workgroup of the launch: `launchBlock` = its entry of the block table.
 template <bool INSTR>
 DEV void primaryBlock(const KParams& P, uint32_t launchBlock, uint32_t* lds) {
@@ -1243,7 +1243,10 @@ DEV v3 SampleEnvironmentMap(const KParams& P, v3 dir) {  // RS:102-117
 // AccumulateFrames' running average (PostProcessor.compute:10-19) of the colour it stores.  Both are what the separate
 // kernels would do to this pixel, in the same order.
 template <bool INSTR, bool XFER = false, bool ACC = false>
-__global__ __launch_bounds__(256, 4) void k_trace_rays(const KParams P) {
+#ifndef RT_TRACE_WAVES
+#define RT_TRACE_WAVES 4   // (3: 133 registers and no spilled value at all, 269 against 243 us)
+#endif
+__global__ __launch_bounds__(256, RT_TRACE_WAVES) void k_trace_rays(const KParams P) {
     extern __shared__ uint32_t lds[];
     const Pixel px = pixelOfThread(P);
     uint32_t rays = 0, pops = 0, bvc = 0, objv = 0, trii = 0, tric = 0, iters = 0, steps = 0;
