@@ -130,6 +130,12 @@ int rt_set_overlap(rt_ctx ctx, int mode);
  *   "table_refresh_frames"       (default 8)  the regions are ranked anew every so many InitialTrace dispatches (into a
  *                                 second pair of tables, so that the frames in flight keep theirs: a refresh that made
  *                                 the frame wait for the one before cost 0.1 ms, 12 us per frame at 8)
+ *   "device_pool_mb"             (RT_DEVICE_POOL_MB, default a sixteenth of the device's memory) released device memory
+ *                                 (buffers, textures, their copies, the arrays derived from a scene) is kept, up to this
+ *                                 many MiB per context, for the next allocation of the same size instead of going
+ *                                 through hipFree and hipMalloc: a scene reload releases and re-creates every buffer
+ *                                 (80k-triangle scene at 1080p: the frame that reloads 8.5 -> 3.8 ms).  0: keep nothing
+ *                                 (what is kept is freed at once).  rt_destroy frees whatever is kept
  *   "debug_stream_delay_us"      (default 0) test aid: before about every second launch its stream is held up for a
  *                                 pseudo-random time of up to this many microseconds (at most 2000), so that a missing
  *                                 order between launches of frames in flight shows as a wrong image

@@ -20,6 +20,7 @@
 #include <atomic>
 #include <memory>
 #include <thread>
+#include <unordered_map>
 #include <vector>
 
 #include "../../include/rt_native.h"
@@ -249,6 +250,12 @@ struct rt_ctx_s {
     static constexpr size_t MAX_PREPS = 4;
     std::vector<Prep> preps;
     uint64_t prepClock = 0;
+    // Device memory the context has let go of, kept for the next allocation of the same size (see devAlloc).
+    struct DevPool {
+        std::multimap<size_t, void*> idle;            // by (rounded) size
+        std::unordered_map<void*, size_t> sizeOf;     // every block devAlloc has handed out and not yet taken back
+        size_t idleBytes = 0, capBytes = 0;
+    } pool;
 };
 
 struct rt_buffer_s {
@@ -309,6 +316,59 @@ int fail(rt_ctx ctx, int code, const char* fmt, ...) {
 int useDevice(rt_ctx ctx) {
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     return RT_OK;
+}
+
+// Device allocations that come and go with the host's buffers.  A scene reload (Main.SetData) releases every buffer
+// and creates buffers of the same sizes again; hipFree and hipMalloc cost 130 and 60 us a call, about thirty calls of
+// each per reload, which is most of what a reload of a small scene takes.  So a released block is kept (up to
+// pool.capBytes in all) and handed to the next request for exactly its size.  A block may be handed out while work
+// that used it is still enqueued: whoever takes a block first writes it on stream0 behind everything the context has
+// enqueued (S(ctx): the clearing of a new buffer, a conversion, the scene's derived arrays), so the order of effects
+// is the streams' order, as with memory fresh from hipMalloc.  hipMalloc running out of memory empties the pool and
+// is tried again.
+void devPoolTrim(rt_ctx ctx, size_t keepBytes) {
+    auto& pool = ctx->pool;
+    while (pool.idleBytes > keepBytes && !pool.idle.empty()) {
+        auto it = std::prev(pool.idle.end());   // largest first
+        hipError_t e = hipFree(it->second);
+        (void)e;
+        pool.idleBytes -= it->first;
+        pool.idle.erase(it);
+    }
+}
+hipError_t devAlloc(rt_ctx ctx, void** p, size_t bytes) {
+    auto& pool = ctx->pool;
+    *p = nullptr;
+    const size_t size = ((bytes ? bytes : 1) + 255) & ~(size_t)255;
+    auto it = pool.idle.find(size);
+    if (it != pool.idle.end()) {
+        *p = it->second;
+        pool.idle.erase(it);
+        pool.idleBytes -= size;
+        pool.sizeOf[*p] = size;
+        return hipSuccess;
+    }
+    hipError_t e = hipMalloc(p, size);
+    if (e == hipErrorOutOfMemory && !pool.idle.empty()) {
+        e = hipGetLastError();   // (clears it)
+        devPoolTrim(ctx, 0);
+        e = hipMalloc(p, size);
+    }
+    if (e == hipSuccess) pool.sizeOf[*p] = size;
+    else *p = nullptr;
+    return e;
+}
+hipError_t devFree(rt_ctx ctx, void* p) {
+    if (!p) return hipSuccess;
+    auto& pool = ctx->pool;
+    auto it = pool.sizeOf.find(p);
+    if (it == pool.sizeOf.end()) return hipFree(p);
+    const size_t size = it->second;
+    pool.sizeOf.erase(it);
+    if (pool.idleBytes + size > pool.capBytes) return hipFree(p);
+    pool.idle.emplace(size, p);
+    pool.idleBytes += size;
+    return hipSuccess;
 }
 int traceStreamIndex(rt_ctx ctx, hipStream_t s) {
     for (int k = 0; k < MAX_FRAMES; k++) if (s == ctx->frameStream[k] && s) return k;
@@ -553,11 +613,11 @@ OtherCopies otherCopiesOf(rt_buffer b) {
     }
     return o;
 }
-void freeCopies(Copies& c) {
+void freeCopies(rt_ctx ctx, Copies& c) {
     hipError_t e = hipSuccess;
     for (int i = 0; i < MAX_FRAMES - 1; i++) {
-        if (c.alt[i]) e = hipFree(c.alt[i]);
-        if (c.tag[i]) e = hipFree(c.tag[i]);
+        if (c.alt[i]) e = devFree(ctx, c.alt[i]);
+        if (c.tag[i]) e = devFree(ctx, c.tag[i]);
         c.alt[i] = nullptr; c.tag[i] = nullptr;
     }
     (void)e;
@@ -575,10 +635,10 @@ void launchToAos(rt_buffer b, void* dst, int64_t first = 0, int64_t n = -1) {
 // A record buffer goes back to a single copy.
 void dropCopies(rt_buffer b) {
     hipError_t e = hipSuccess;
-    if (b->tag) e = hipFree(b->tag);
+    if (b->tag) e = devFree(b->ctx, b->tag);
     (void)e;
     b->tag = nullptr;
-    freeCopies(b->more);
+    freeCopies(b->ctx, b->more);
     auto& v = b->ctx->tagged;
     v.erase(std::remove(v.begin(), v.end(), b), v.end());
 }
@@ -608,7 +668,7 @@ int convertLayout(rt_buffer b, int target) {
     if (b->stride != 52) return fail(ctx, RT_ERR_INVALID_ARG, "buffer stride %d cannot hold a 52-byte per-pixel record", b->stride);
     if (b->layout != LAYOUT_AOS && target != LAYOUT_AOS) return fail(ctx, RT_ERR_INVALID_ARG, "buffer is bound as two different record types");
     void* tmp = nullptr;
-    HIP_TRY(ctx, hipMalloc(&tmp, layoutBytes(b, target)));
+    HIP_TRY(ctx, devAlloc(ctx, &tmp, layoutBytes(b, target)));
     int blocks = (int)((b->count + 255) / 256);
     rt_buffer_s shadow = *b;
     shadow.dev = tmp;
@@ -624,14 +684,14 @@ int convertLayout(rt_buffer b, int target) {
     hipError_t e = hipGetLastError();
     if (e == hipSuccess) e = hipStreamSynchronize(S(ctx));
     if (e != hipSuccess) {
-        hipError_t e2 = hipFree(tmp);
+        hipError_t e2 = devFree(ctx, tmp);
         (void)e2;
         return fail(ctx, RT_ERR_NO_DEVICE, "layout conversion failed: %s", hipGetErrorString(e));
     }
-    HIP_TRY(ctx, hipFree(b->dev));
+    HIP_TRY(ctx, devFree(ctx, b->dev));
     b->dev = tmp;
     if (b->tag) dropCopies(b);   // the tagged copies of the records have just been merged into `tmp`: one copy again
-    else if (b->more.n && layoutBytes(b, target) != layoutBytes(b, b->layout)) freeCopies(b->more);   // copies of another size are of no use
+    else if (b->more.n && layoutBytes(b, target) != layoutBytes(b, b->layout)) freeCopies(ctx, b->more);   // copies of another size are of no use
     b->layout = target;
     return RT_OK;
 }
@@ -757,7 +817,7 @@ int prepareScene(rt_shader sh, int kernel, KParams& P, bool ris = false) {
         if (sceneStart >= nNodes) return fail(ctx, RT_ERR_BAD_SCENE, "SceneBVHStartIndex %u is outside the BVs buffer", sceneStart);
         {
             void* scratchDev = nullptr;   // links, then one flag word
-            HIP_TRY(ctx, hipMalloc(&scratchDev, nNodes * sizeof(Link) + 16));
+            HIP_TRY(ctx, devAlloc(ctx, &scratchDev, nNodes * sizeof(Link) + 16));
             uint32_t* flagDev = (uint32_t*)((char*)scratchDev + nNodes * sizeof(Link));
             uint32_t flag = 0;
             hipError_t e = hipMemsetAsync(flagDev, 0, 4, S(ctx));
@@ -770,7 +830,7 @@ int prepareScene(rt_shader sh, int kernel, KParams& P, bool ris = false) {
             if (e == hipSuccess) e = hipMemcpyAsync(&flag, flagDev, 4, hipMemcpyDeviceToHost, S(ctx));
             if (e == hipSuccess) e = hipMemcpyAsync(objs.data(), bObjs->dev, objs.size() * sizeof(rt_scene_object), hipMemcpyDeviceToHost, S(ctx));
             if (e == hipSuccess) e = hipStreamSynchronize(S(ctx));
-            hipError_t e2 = hipFree(scratchDev);
+            hipError_t e2 = devFree(ctx, scratchDev);
             (void)e2;
             if (e != hipSuccess) return fail(ctx, RT_ERR_NO_DEVICE, "reading the scene back for validation failed: %s", hipGetErrorString(e));
             if (flag) return fail(ctx, RT_ERR_BAD_SCENE, "a triangle's vertex index is outside the Vertices buffer");
@@ -818,8 +878,8 @@ int prepareScene(rt_shader sh, int kernel, KParams& P, bool ris = false) {
 
         auto ensure = [&](void** p, size_t* have, size_t need) -> int {
             if (*have >= need && *p) return RT_OK;
-            if (*p) { hipError_t e = hipFree(*p); (void)e; *p = nullptr; *have = 0; }
-            HIP_TRY(ctx, hipMalloc(p, need));
+            if (*p) { hipError_t e = devFree(ctx, *p); (void)e; *p = nullptr; *have = 0; }
+            HIP_TRY(ctx, devAlloc(ctx, p, need));
             *have = need;
             return RT_OK;
         };
@@ -1270,18 +1330,18 @@ bool ensureCopies(rt_ctx ctx, Copies& c, size_t bytes, int want, uint32_t** tagO
     want = want > MAX_FRAMES ? MAX_FRAMES : want;
     const size_t tagBytes = (size_t)count * sizeof(uint32_t);
     if (tagOfCurrent && !*tagOfCurrent && want >= 2) {
-        if (hipMalloc((void**)tagOfCurrent, tagBytes) != hipSuccess) { *tagOfCurrent = nullptr; return false; }
+        if (devAlloc(ctx, (void**)tagOfCurrent, tagBytes) != hipSuccess) { *tagOfCurrent = nullptr; return false; }
         if (hipMemsetD32Async((hipDeviceptr_t)*tagOfCurrent, 1, (size_t)count, S(ctx)) != hipSuccess) return false;
     }
     while (c.n + 1 < want) {
         void* p = nullptr;
         uint32_t* t = nullptr;
-        if (hipMalloc(&p, bytes) != hipSuccess) return false;
-        if (tagOfCurrent && hipMalloc((void**)&t, tagBytes) != hipSuccess) { hipError_t e = hipFree(p); (void)e; return false; }
+        if (devAlloc(ctx, &p, bytes) != hipSuccess) return false;
+        if (tagOfCurrent && devAlloc(ctx, (void**)&t, tagBytes) != hipSuccess) { hipError_t e = devFree(ctx, p); (void)e; return false; }
         // (rows a banded launch never writes must not hold garbage a readback could return)
         bool ok = hipMemsetAsync(p, 0, bytes, S(ctx)) == hipSuccess;
         if (t) ok = ok && hipMemsetAsync(t, 0, tagBytes, S(ctx)) == hipSuccess;
-        if (!ok) { hipError_t e = hipFree(p); if (t) e = hipFree(t); (void)e; return false; }
+        if (!ok) { hipError_t e = devFree(ctx, p); if (t) e = devFree(ctx, t); (void)e; return false; }
         for (int i = c.n; i > 0; i--) { c.alt[i] = c.alt[i - 1]; c.tag[i] = c.tag[i - 1]; }
         c.alt[0] = p; c.tag[0] = t;
         c.n++;
@@ -1907,6 +1967,12 @@ int rt_create(int device_id, rt_ctx* out) {
             return RT_ERR_NO_DEVICE;
         }
     }
+    {   // released device memory kept for reuse: a sixteenth of the device's memory at most (RT_DEVICE_POOL_MB overrides, 0 = none)
+        size_t freeB = 0, totalB = 0;
+        if (hipMemGetInfo(&freeB, &totalB) != hipSuccess) totalB = (size_t)64 << 30;
+        static const long poolMb = [] { const char* e = getenv("RT_DEVICE_POOL_MB"); return e ? atol(e) : -1L; }();
+        ctx->pool.capBytes = poolMb >= 0 ? (size_t)poolMb << 20 : totalB / 16;
+    }
     // this device's copy of the file-scope scratch array (every GPU has its own, at its own address)
     if (hipGetSymbolAddress((void**)&ctx->scratch, HIP_SYMBOL(scratch)) != hipSuccess || !ctx->scratch) {
         rt_destroy(ctx);
@@ -1927,10 +1993,12 @@ void rt_destroy(rt_ctx ctx) {
         for (auto& o : scratchOwner) if (o == ctx) o = nullptr;
     }
     for (auto& pr : ctx->preps) {
-        if (pr.wide) e = hipFree(pr.wide);
-        if (pr.btri) e = hipFree(pr.btri);
-        if (pr.objRoot) e = hipFree(pr.objRoot);
+        if (pr.wide) e = devFree(ctx, pr.wide);
+        if (pr.btri) e = devFree(ctx, pr.btri);
+        if (pr.objRoot) e = devFree(ctx, pr.objRoot);
     }
+    ctx->pool.capBytes = 0;
+    devPoolTrim(ctx, 0);
     if (ctx->statsDev) e = hipFree(ctx->statsDev);
     if (ctx->bgCounter) e = hipFree(ctx->bgCounter);
     for (rt_shader sh : ctx->shaders) sh->ctx = nullptr;   // a shader closed after its context only frees itself
@@ -2064,6 +2132,11 @@ int rt_set_tuning(rt_ctx ctx, const char* name, int value) {
         HIP_TRY(ctx, hipStreamSynchronize(S(ctx)));
         freeBlockMaps(ctx);
         ctx->regionBlocks[!strcmp(name, "region_blocks_reuse") ? 0 : !strcmp(name, "region_blocks_primary") ? 1 : 2] = value;
+    }
+    else if (!strcmp(name, "device_pool_mb")) {   // released device memory kept for reuse at most; what is kept beyond it is freed now
+        if (value < 0) return fail(ctx, RT_ERR_INVALID_ARG, "device_pool_mb must not be negative");
+        ctx->pool.capBytes = (size_t)value << 20;
+        devPoolTrim(ctx, ctx->pool.capBytes);
     }
     else if (!strcmp(name, "one_wave_groups")) {
         if (value < 0 || value > 31) return fail(ctx, RT_ERR_INVALID_ARG, "one_wave_groups is a mask of bits 0 to 4");
@@ -2294,10 +2367,10 @@ int rt_buffer_create(rt_ctx ctx, int64_t count, int stride, rt_buffer* out) {
     b->ctx = ctx; b->count = count; b->stride = stride; b->bytes = (size_t)count * stride; b->layout = LAYOUT_AOS;
     b->version = ctx->versionCounter++;
     b->dev = nullptr;
-    hipError_t e = hipMalloc(&b->dev, b->bytes);
+    hipError_t e = devAlloc(ctx, &b->dev, b->bytes);
     if (e == hipSuccess) e = hipMemsetAsync(b->dev, 0, b->bytes, S(ctx));
     if (e != hipSuccess) {
-        if (b->dev) { hipError_t e2 = hipFree(b->dev); (void)e2; }
+        if (b->dev) { hipError_t e2 = devFree(ctx, b->dev); (void)e2; }
         delete b;
         return fail(ctx, e == hipErrorOutOfMemory ? RT_ERR_OUT_OF_MEMORY : RT_ERR_NO_DEVICE, "buffer allocation of %zu bytes failed: %s", (size_t)count * stride, hipGetErrorString(e));
     }
@@ -2338,12 +2411,12 @@ int rt_buffer_get_data(rt_buffer b, void* dst, size_t bytes) {
         return finish(ctx);
     }
     void* tmp = nullptr;
-    HIP_TRY(ctx, hipMalloc(&tmp, b->bytes));
+    HIP_TRY(ctx, devAlloc(ctx, &tmp, b->bytes));
     launchToAos(b, tmp);
     hipError_t e = hipGetLastError();
     if (e == hipSuccess) e = hipMemcpyAsync(dst, tmp, bytes, hipMemcpyDeviceToHost, S(ctx));
     if (e == hipSuccess) e = hipStreamSynchronize(S(ctx));
-    hipError_t e2 = hipFree(tmp);
+    hipError_t e2 = devFree(ctx, tmp);
     (void)e2;
     if (e != hipSuccess) return fail(ctx, RT_ERR_NO_DEVICE, "buffer readback failed: %s", hipGetErrorString(e));
     return finish(ctx);
@@ -2365,12 +2438,12 @@ int rt_buffer_get_range(rt_buffer b, void* dst, int64_t first, int64_t count) {
         return finish(ctx);
     }
     void* tmp = nullptr;
-    HIP_TRY(ctx, hipMalloc(&tmp, bytes));
+    HIP_TRY(ctx, devAlloc(ctx, &tmp, bytes));
     launchToAos(b, tmp, first, count);
     hipError_t e = hipGetLastError();
     if (e == hipSuccess) e = hipMemcpyAsync(dst, tmp, bytes, hipMemcpyDeviceToHost, S(ctx));
     if (e == hipSuccess) e = hipStreamSynchronize(S(ctx));
-    hipError_t e2 = hipFree(tmp);
+    hipError_t e2 = devFree(ctx, tmp);
     (void)e2;
     if (e != hipSuccess) return fail(ctx, RT_ERR_NO_DEVICE, "buffer readback failed: %s", hipGetErrorString(e));
     return finish(ctx);
@@ -2390,14 +2463,14 @@ void rt_buffer_release(rt_buffer b) {
             for (auto it = table.begin(); it != table.end();) it = it->second == b ? table.erase(it) : std::next(it);
     for (auto& pr : ctx->preps) {
         if (pr.pBVs != b->dev && pr.pTris != b->dev && pr.pVerts != b->dev && pr.pObjs != b->dev) continue;
-        if (pr.wide) e = hipFree(pr.wide);
-        if (pr.btri) e = hipFree(pr.btri);
-        if (pr.objRoot) e = hipFree(pr.objRoot);
+        if (pr.wide) e = devFree(ctx, pr.wide);
+        if (pr.btri) e = devFree(ctx, pr.btri);
+        if (pr.objRoot) e = devFree(ctx, pr.objRoot);
         pr = rt_ctx_s::Prep();
     }
     if (b->tag) dropCopies(b);
-    freeCopies(b->more);
-    if (b->dev) e = hipFree(b->dev);
+    freeCopies(ctx, b->more);
+    if (b->dev) e = devFree(ctx, b->dev);
     (void)e;
     delete b;
 }
@@ -2416,10 +2489,10 @@ int rt_texture_create(rt_ctx ctx, int w, int h, rt_format format, rt_texture* ou
     t->version = ctx->versionCounter++;
     t->bytes = (size_t)w * h * (format == RT_FORMAT_R32F ? 4 : 16);
     t->dev = nullptr;
-    hipError_t e = hipMalloc(&t->dev, t->bytes);
+    hipError_t e = devAlloc(ctx, &t->dev, t->bytes);
     if (e == hipSuccess) e = hipMemsetAsync(t->dev, 0, t->bytes, S(ctx));
     if (e != hipSuccess) {
-        if (t->dev) { hipError_t e2 = hipFree(t->dev); (void)e2; }
+        if (t->dev) { hipError_t e2 = devFree(ctx, t->dev); (void)e2; }
         delete t;
         return fail(ctx, e == hipErrorOutOfMemory ? RT_ERR_OUT_OF_MEMORY : RT_ERR_NO_DEVICE, "texture allocation failed: %s", hipGetErrorString(e));
     }
@@ -2436,14 +2509,14 @@ int rt_texture_set_data(rt_texture t, const void* src, size_t bytes) {
     if (t->format == RT_FORMAT_RGBA8_UNORM) {
         if (bytes != (size_t)n * 4) return fail(ctx, RT_ERR_INVALID_ARG, "RGBA8 texture upload must be %lld bytes", (long long)n * 4);
         void* tmp = nullptr;
-        HIP_TRY(ctx, hipMalloc(&tmp, bytes));
+        HIP_TRY(ctx, devAlloc(ctx, &tmp, bytes));
         hipError_t e = hipMemcpyAsync(tmp, src, bytes, hipMemcpyHostToDevice, S(ctx));
         if (e == hipSuccess) {
             hipLaunchKernelGGL(k_rgba8_to_f32, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, S(ctx), (const uint8_t*)tmp, (float4*)t->dev, n);
             e = hipGetLastError();
         }
         if (e == hipSuccess) e = hipStreamSynchronize(S(ctx));
-        hipError_t e2 = hipFree(tmp);
+        hipError_t e2 = devFree(ctx, tmp);
         (void)e2;
         if (e != hipSuccess) return fail(ctx, RT_ERR_NO_DEVICE, "texture upload failed: %s", hipGetErrorString(e));
         return finish(ctx);
@@ -2489,8 +2562,8 @@ void rt_texture_release(rt_texture t) {
     for (rt_shader sh : ctx->shaders)   // as rt_buffer_release: no binding may keep the handle
         for (auto& table : sh->textures)
             for (auto it = table.begin(); it != table.end();) it = it->second == t ? table.erase(it) : std::next(it);
-    if (t->dev) e = hipFree(t->dev);
-    freeCopies(t->more);
+    if (t->dev) e = devFree(ctx, t->dev);
+    freeCopies(ctx, t->more);
     (void)e;
     delete t;
 }

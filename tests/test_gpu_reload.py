@@ -211,3 +211,51 @@ def test_flush_launches_what_is_held(gpu_ctx, scene_small):
         gpu_ctx.set_fusion(True)
         gpu_ctx.set_tuning("frames_in_flight", 2)   # (this test no longer uses the stream it took: frames may alternate again)
         drv.close()
+
+
+def _device_free_bytes():
+    """hipMemGetInfo: free bytes of the current device."""
+    hip = C.CDLL("libamdhip64.so")
+    free, total = C.c_size_t(0), C.c_size_t(0)
+    assert hip.hipMemGetInfo(C.byref(free), C.byref(total)) == 0
+    return free.value
+
+
+@pytest.mark.parametrize("pool_mb", [None, 0])
+def test_reloads_reuse_released_device_memory(pool_mb):
+    """A reload releases every buffer and creates buffers of the same sizes again: the library keeps what was released
+    for them (device_pool_mb; 0 = every release is a hipFree), and the frames are the oracle's either way."""
+    scene = rt.build_scene_s0(subdivide=False)
+    cfg = h.small_config(512, 288)   # (per-pixel buffers of several MB: hipMemGetInfo does not see small blocks come and go)
+    ctx = rt.RtContext(0)
+    if pool_mb is not None:
+        ctx.set_tuning("device_pool_mb", pool_mb)
+    drv = rt.Driver(ctx, cfg, scene)
+    orc = h.OracleRenderer(scene.arrays(), cfg)
+    try:
+        for _ in range(2):
+            drv.render_frame(); orc.render_frame()
+        free = []
+        for k in range(3):
+            drv.reload(); orc.reload(None)
+            for _ in range(2):
+                drv.render_frame(); orc.render_frame()
+            compare(drv, orc, f"after reload {k}")
+            free.append(_device_free_bytes())
+        if pool_mb is None:
+            # everything the second and third reload created came out of what the reload before had released
+            assert abs(free[1] - free[0]) <= (2 << 20) and abs(free[2] - free[0]) <= (2 << 20), free
+            held = free[0]
+            ctx.set_tuning("device_pool_mb", 0)     # ... and what is kept idle goes back to the device on request
+            assert _device_free_bytes() > held
+            drv.reload(); orc.reload(None)
+            drv.render_frame(); orc.render_frame()
+            compare(drv, orc, "after a reload without the pool")
+    finally:
+        drv.close()
+        ctx.close()
+
+
+def test_device_pool_argument_is_checked(gpu_ctx):
+    with pytest.raises(rt.NativeError):
+        gpu_ctx.set_tuning("device_pool_mb", -1)
