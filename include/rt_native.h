@@ -134,7 +134,7 @@ int rt_set_overlap(rt_ctx ctx, int mode);
  *                                 (buffers, textures, their copies, the arrays derived from a scene) is kept, up to this
  *                                 many MiB per context, for the next allocation of the same size instead of going
  *                                 through hipFree and hipMalloc: a scene reload releases and re-creates every buffer
- *                                 (80k-triangle scene at 1080p: the frame that reloads 8.5 -> 3.8 ms).  0: keep nothing
+ *                                 (80k-triangle scene at 1080p: the frame that reloads 8.5 -> 3.1 ms).  0: keep nothing
  *                                 (what is kept is freed at once).  rt_destroy frees whatever is kept
  *   "debug_stream_delay_us"      (default 0) test aid: before about every second launch its stream is held up for a
  *                                 pseudo-random time of up to this many microseconds (at most 2000), so that a missing

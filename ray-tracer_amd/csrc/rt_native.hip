@@ -252,9 +252,11 @@ struct rt_ctx_s {
     uint64_t prepClock = 0;
     // Device memory the context has let go of, kept for the next allocation of the same size (see devAlloc).
     struct DevPool {
-        std::multimap<size_t, void*> idle;            // by (rounded) size
+        struct Idle { void* p; uint64_t stamp; };
+        std::multimap<size_t, Idle> idle;             // by size class
         std::unordered_map<void*, size_t> sizeOf;     // every block devAlloc has handed out and not yet taken back
         size_t idleBytes = 0, capBytes = 0;
+        uint64_t clock = 0;
     } pool;
 };
 
@@ -273,6 +275,7 @@ struct rt_buffer_s {
     uint32_t* tag = nullptr;     // of the copy `dev` (those of the others: more.tag)
     int tagGroup = 4;            // float4s per tag: a 64-byte reservoir record, or the candidates of one pixel ray (RIS)
     uint64_t epoch = 0;          // rt_ctx_s::epoch when the copies last changed places
+    bool zeroed = false;         // still as rt_buffer_create cleared it: nothing has been uploaded, dispatched on or mapped
 };
 
 struct rt_texture_s {
@@ -321,28 +324,37 @@ int useDevice(rt_ctx ctx) {
 // Device allocations that come and go with the host's buffers.  A scene reload (Main.SetData) releases every buffer
 // and creates buffers of the same sizes again; hipFree and hipMalloc cost 130 and 60 us a call, about thirty calls of
 // each per reload, which is most of what a reload of a small scene takes.  So a released block is kept (up to
-// pool.capBytes in all) and handed to the next request for exactly its size.  A block may be handed out while work
-// that used it is still enqueued: whoever takes a block first writes it on stream0 behind everything the context has
-// enqueued (S(ctx): the clearing of a new buffer, a conversion, the scene's derived arrays), so the order of effects
-// is the streams' order, as with memory fresh from hipMalloc.  hipMalloc running out of memory empties the pool and
-// is tried again.
-void devPoolTrim(rt_ctx ctx, size_t keepBytes) {
+// pool.capBytes in all, the blocks released longest ago making room) and handed to the next request of its size
+// class.  Sizes are rounded up to sixteen classes per power of two (at most 6 % more than asked for): the ReSTIR
+// project's BVs buffer grows by a few nodes with every reload (its builder appends the new scene BVH), and a block
+// that never fits again would only fill the list.  A block may be handed out while work that used it is still
+// enqueued: whoever takes a block first writes it on stream0 behind everything the context has enqueued (S(ctx): the
+// clearing of a new buffer, a conversion, the scene's derived arrays), so the order of effects is the streams' order,
+// as with memory fresh from hipMalloc.  hipMalloc running out of memory empties the list and is tried again.
+size_t devSizeClass(size_t bytes) {
+    if (bytes <= 4096) return 4096;
+    int top = 63 - __builtin_clzll((unsigned long long)bytes);   // 2^top <= bytes
+    const size_t step = (size_t)1 << (top - 4);
+    return (bytes + step - 1) & ~(step - 1);
+}
+void devPoolTrim(rt_ctx ctx, size_t keepBytes) {   // the blocks released longest ago go first
     auto& pool = ctx->pool;
     while (pool.idleBytes > keepBytes && !pool.idle.empty()) {
-        auto it = std::prev(pool.idle.end());   // largest first
-        hipError_t e = hipFree(it->second);
+        auto oldest = pool.idle.begin();
+        for (auto it = pool.idle.begin(); it != pool.idle.end(); ++it) if (it->second.stamp < oldest->second.stamp) oldest = it;
+        hipError_t e = hipFree(oldest->second.p);
         (void)e;
-        pool.idleBytes -= it->first;
-        pool.idle.erase(it);
+        pool.idleBytes -= oldest->first;
+        pool.idle.erase(oldest);
     }
 }
 hipError_t devAlloc(rt_ctx ctx, void** p, size_t bytes) {
     auto& pool = ctx->pool;
     *p = nullptr;
-    const size_t size = ((bytes ? bytes : 1) + 255) & ~(size_t)255;
+    const size_t size = devSizeClass(bytes);
     auto it = pool.idle.find(size);
     if (it != pool.idle.end()) {
-        *p = it->second;
+        *p = it->second.p;
         pool.idle.erase(it);
         pool.idleBytes -= size;
         pool.sizeOf[*p] = size;
@@ -365,8 +377,9 @@ hipError_t devFree(rt_ctx ctx, void* p) {
     if (it == pool.sizeOf.end()) return hipFree(p);
     const size_t size = it->second;
     pool.sizeOf.erase(it);
-    if (pool.idleBytes + size > pool.capBytes) return hipFree(p);
-    pool.idle.emplace(size, p);
+    if (size > pool.capBytes) return hipFree(p);
+    devPoolTrim(ctx, pool.capBytes - size);
+    pool.idle.emplace(size, rt_ctx_s::DevPool::Idle{p, ++pool.clock});
     pool.idleBytes += size;
     return hipSuccess;
 }
@@ -667,6 +680,21 @@ int convertLayout(rt_buffer b, int target) {
                                               "dispatch the kernel once with rt_dispatch after creating or uploading the buffer");
     if (b->stride != 52) return fail(ctx, RT_ERR_INVALID_ARG, "buffer stride %d cannot hold a 52-byte per-pixel record", b->stride);
     if (b->layout != LAYOUT_AOS && target != LAYOUT_AOS) return fail(ctx, RT_ERR_INVALID_ARG, "buffer is bound as two different record types");
+    if (b->zeroed && !b->tag && b->more.n == 0) {
+        // a buffer nobody has written since it was created (every buffer after a scene reload): zeros are zeros in every
+        // layout, so there is nothing to convert, and nothing to wait for
+        const size_t need = layoutBytes(b, target);
+        if (need != layoutBytes(b, b->layout)) {
+            void* fresh = nullptr;
+            HIP_TRY(ctx, devAlloc(ctx, &fresh, need));
+            hipError_t e = hipMemsetAsync(fresh, 0, need, S(ctx));
+            if (e != hipSuccess) { hipError_t e2 = devFree(ctx, fresh); (void)e2; return fail(ctx, RT_ERR_NO_DEVICE, "clearing a buffer failed: %s", hipGetErrorString(e)); }
+            HIP_TRY(ctx, devFree(ctx, b->dev));
+            b->dev = fresh;
+        }
+        b->layout = target;
+        return RT_OK;
+    }
     void* tmp = nullptr;
     HIP_TRY(ctx, devAlloc(ctx, &tmp, layoutBytes(b, target)));
     int blocks = (int)((b->count + 255) / 256);
@@ -934,6 +962,7 @@ int needPlanes(rt_shader sh, int kernel, const char* name, int layout, Planes& o
     if (!b) return fail(sh->ctx, RT_ERR_UNBOUND, "kernel %d: buffer '%s' is not bound", kernel, name);
     int rc = convertLayout(b, layout);
     if (rc) return rc;
+    b->zeroed = false;   // (the kernel may write it)
     out = planesOf(b);
     return RT_OK;
 }
@@ -944,6 +973,7 @@ int needRecs(rt_shader sh, int kernel, const char* name, Recs& out, bool duringF
     if (!b) return fail(sh->ctx, RT_ERR_UNBOUND, "kernel %d: buffer '%s' is not bound", kernel, name);
     int rc = convertLayout(b, LAYOUT_RESERVOIR_RECS);
     if (rc) return rc;
+    b->zeroed = false;
     if (duringFrame && b->epoch != sh->ctx->epoch) joinOthers(sh->ctx);
     out = recsOf(b);
     return RT_OK;
@@ -2369,6 +2399,7 @@ int rt_buffer_create(rt_ctx ctx, int64_t count, int stride, rt_buffer* out) {
     b->dev = nullptr;
     hipError_t e = devAlloc(ctx, &b->dev, b->bytes);
     if (e == hipSuccess) e = hipMemsetAsync(b->dev, 0, b->bytes, S(ctx));
+    b->zeroed = e == hipSuccess;
     if (e != hipSuccess) {
         if (b->dev) { hipError_t e2 = devFree(ctx, b->dev); (void)e2; }
         delete b;
@@ -2391,6 +2422,7 @@ int rt_buffer_set_data(rt_buffer b, const void* src, size_t bytes) {
         dropCopies(b);
     }
     if ((rc = convertLayout(b, LAYOUT_AOS))) return rc;
+    b->zeroed = false;
     // synchronous copy: the caller may reuse `src` as soon as this returns
     HIP_TRY(ctx, hipMemcpyAsync(b->dev, src, bytes, hipMemcpyHostToDevice, S(ctx)));
     HIP_TRY(ctx, hipStreamSynchronize(S(ctx)));
@@ -2574,6 +2606,7 @@ int rt_buffer_map_rows(rt_buffer b, int width, int row0, int row1, rt_segment ou
     if (width < 1 || row0 < 0 || row1 < row0 || (int64_t)row1 * width > b->count)
         return fail(ctx, RT_ERR_INVALID_ARG, "rows [%d,%d) of width %d are outside the buffer", row0, row1, width);
     SK(ctx);   // whoever reads through these pointers orders itself against the stream: nothing may still be held back
+    b->zeroed = false;   // (the host may write through them)
     const size_t first = (size_t)row0 * width, n = (size_t)(row1 - row0) * width;
     // An object with two copies: the address is that of the current copy.  Unless the context renders row bands beside
     // one another (overlap 2, where the rows a band does not own are undefined in such objects anyway), that copy is
