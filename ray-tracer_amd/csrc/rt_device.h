@@ -26,6 +26,19 @@ namespace rtn {
 constexpr uint32_t ENTRY_LEAF = 0x80000000u;
 constexpr uint32_t ENTRY_LEAF_INDIRECT = 0x40000000u;
 constexpr uint32_t ENTRY_INDEX_MASK = 0x3fffffffu;
+// Top of the tree in LDS (an alternative that is measured, not the default: rt_set_tuning "top_nodes_lds").  The first
+// TOP_MAX internal nodes in breadth-first order from the scene root - through the scene-level leaves into the mesh BVHs
+// of the objects - have a copy of their wide record in a small table that every wave of a launch loads into LDS.  An
+// internal entry with ENTRY_TOP set names a slot of that table instead of a BV index (BV indices stay below 2^26).  Only
+// records of the table, the scene root entry and the objects' root entries ever hold such an entry (a node's parent comes
+// before it in breadth-first order), so the wide array itself and the kernels that do not use the table are untouched.
+constexpr uint32_t ENTRY_TOP = 0x20000000u;
+constexpr int TOP_MAX = 64;
+struct TopPlan {
+    uint32_t node[TOP_MAX];             // slot -> BV index
+    int16_t slotA[TOP_MAX], slotB[TOP_MAX];   // slot of each child, -1 when the child is not in the table (or a leaf)
+    int n;
+};
 constexpr int ENTRY_INLINE_MAX_COUNT = 31;
 constexpr int ENTRY_INLINE_MAX_START = (1 << 26) - 1;
 
@@ -91,6 +104,10 @@ struct KParams {
     const rt_vertex* verts; int64_t nVerts;
     uint32_t sceneRootEntry;
     int stackDepth;  // dwords of LDS stack per lane
+    // top of the tree in LDS (see ENTRY_TOP): the table, its slots in use (0: none), and the entries that lead into it
+    const float4* top; int topCount;
+    const uint32_t* objRootEntryTop;
+    uint32_t sceneRootEntryTop;
     Tex atlas, env;
     // per-pixel state
     Planes hit, temporal;

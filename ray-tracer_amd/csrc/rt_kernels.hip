@@ -385,9 +385,10 @@ struct TravState {
     uint32_t e;              // entry to visit next, or ENTRY_NONE
     uint32_t top;            // newest of the `sp` stacked entries (see travPush)
     int divOk, wDivOk;       // RIS only: the direction of the level being traversed / of the world ray passes divisorsInRange
+    const float4* topLds;    // TOP only: this wave's copy of the table of top nodes (see ENTRY_TOP)
 };
 
-template <bool INSTR, bool RIS = false>
+template <bool INSTR, bool RIS = false, bool TOP = false>
 DEV void travBegin(const KParams& P, TravState& s, Trav& t, v3 wpos, v3 wdir, v3 winv, uint32_t* stk) {
     if (RIS) { winv = rcp3(wdir); s.wDivOk = divisorsInRange(wdir) ? 1 : 0; s.divOk = s.wDivOk; }   // (the RIS callers pass no reciprocal)
     s.wpos = wpos; s.wdir = wdir; s.winv = winv;
@@ -395,7 +396,7 @@ DEV void travBegin(const KParams& P, TravState& s, Trav& t, v3 wpos, v3 wdir, v3
     s.best = INF(); s.worldBest = INF();
     s.sp = stk; s.floor = stk; s.inObj = 0; s.objCur = 0; s.objEnd = 0; s.curObj = -1; s.localTri = -1;
     s.localU = 0; s.localV = 0;
-    s.e = P.sceneRootEntry;
+    s.e = TOP ? P.sceneRootEntryTop : P.sceneRootEntry;
     s.top = ENTRY_NONE;
     t.tri = -1; t.obj = -1; t.steps = 0; t.u = 0; t.v = 0; t.triChecks = 0; t.bvChecks = 0;
     if (INSTR) { t.hash = 2166136261u; t.pops = 1; t.objVisits = 0; t.triIters = 0; t.iters = 0; }
@@ -428,7 +429,7 @@ DEV void travPop(const KParams& P, TravState& s, Trav& t) {
     }
 }
 // Service step of one lane that holds ENTRY_NONE.  Leaves ENTRY_DEAD when the ray is finished.
-template <bool INSTR, bool RIS>
+template <bool INSTR, bool RIS, bool TOP = false>
 DEV void travService(const KParams& P, TravState& s, Trav& t, const uint32_t* stk) {
     if (s.inObj) {  // the object's subtree is exhausted (RS:251-258)
         if (s.best < s.worldBest) { s.worldBest = s.best; t.tri = s.localTri; t.obj = s.curObj; t.u = s.localU; t.v = s.localV; }
@@ -449,7 +450,7 @@ DEV void travService(const KParams& P, TravState& s, Trav& t, const uint32_t* st
         s.curObj = s.objCur;
         s.inObj = 1;
         s.floor = s.sp;
-        s.e = P.objRootEntry[s.objCur];
+        s.e = (TOP ? P.objRootEntryTop : P.objRootEntry)[s.objCur];
         s.objCur++;
         if (INSTR) { t.objVisits++; t.pops++; }
         return;
@@ -459,15 +460,24 @@ DEV void travService(const KParams& P, TravState& s, Trav& t, const uint32_t* st
     if (INSTR) t.pops++;
 }
 // One internal-node step of one lane (RS:195-214).
-template <bool INSTR, bool RIS>
+template <bool INSTR, bool RIS, bool TOP = false>
 DEV void travInternal(const KParams& P, TravState& s, Trav& t, uint32_t* stk) {
+    static_assert(!(INSTR && TOP), "the visit hash is taken over BV indices: the instrumented kernels do not use the table of top nodes");
     const uint32_t e = s.e;
     if (INSTR) { t.iters++; t.hash = (t.hash ^ (0x80000000u | e)) * 16777619u; }
-    // 32-bit byte offset from a uniform base (one shift instead of 64-bit address arithmetic; the scene check keeps
-    // the node and triangle counts below 2^26)
-    const float4* rec = (const float4*)((const char*)P.wide + (e << 6));
-    const float4 q0 = rec[0], q1 = rec[1], q2 = rec[2];
-    const float2 q3 = *(const float2*)(rec + 3);  // the two child entries
+    float4 q0, q1, q2;
+    float2 q3;   // the two child entries
+    if (TOP && (e & ENTRY_TOP)) {   // a slot of the wave's table in LDS
+        const float4* rec = s.topLds + ((e & (uint32_t)(TOP_MAX - 1)) << 2);
+        q0 = rec[0]; q1 = rec[1]; q2 = rec[2];
+        q3 = *(const float2*)(rec + 3);
+    } else {
+        // 32-bit byte offset from a uniform base (one shift instead of 64-bit address arithmetic; the scene check keeps
+        // the node and triangle counts below 2^26)
+        const float4* rec = (const float4*)((const char*)P.wide + (e << 6));
+        q0 = rec[0]; q1 = rec[1]; q2 = rec[2];
+        q3 = *(const float2*)(rec + 3);
+    }
     float dstA, dstB;
     if (RIS) {
         if (!RT_RIS_FAST_DIV || !s.divOk || !RayBVIntersectDivPairFast(s.rpos, s.rdir, s.rinv, q0, q1, q2, dstA, dstB)) {
@@ -541,10 +551,10 @@ DEV void travLeaf(const KParams& P, TravState& s, Trav& t, const uint32_t* stk) 
     travPop<INSTR>(P, s, t);
 }
 // One outer trip: service, internal-node phase, leaf phase.  A lane whose ray has ended holds ENTRY_DEAD (t.dst is set).
-template <bool INSTR, bool RIS>
+template <bool INSTR, bool RIS, bool TOP = false>
 DEV void travTrip(const KParams& P, TravState& s, Trav& t, uint32_t* stk) {
     if (INSTR && __builtin_amdgcn_ballot_w64(s.e == ENTRY_NONE) != 0) t.wSvc++;
-    if (s.e == ENTRY_NONE) travService<INSTR, RIS>(P, s, t, stk);
+    if (s.e == ENTRY_NONE) travService<INSTR, RIS, TOP>(P, s, t, stk);
     // The phase is left once at least RT_LEAF_NUM / RT_LEAF_DEN of the lanes still at work wait for a leaf or for
     // service, i.e. once the lanes holding an internal entry are few enough (the live lanes do not change in it).
     const int nAlive = __builtin_popcountll(__builtin_amdgcn_ballot_w64(s.e != ENTRY_DEAD));
@@ -554,7 +564,7 @@ DEV void travTrip(const KParams& P, TravState& s, Trav& t, uint32_t* stk) {
         do {
             t.steps++;
             if (INSTR) { t.wInt++; t.wIntLanes += (uint32_t)nInt; }
-            if (entryIsInternal(s.e)) travInternal<INSTR, RIS>(P, s, t, stk);
+            if (entryIsInternal(s.e)) travInternal<INSTR, RIS, TOP>(P, s, t, stk);
             nInt = __builtin_popcountll(__builtin_amdgcn_ballot_w64(entryIsInternal(s.e)));
         } while (RT_LEAF_DEN * nInt > (RT_LEAF_DEN - RT_LEAF_NUM) * nAlive);   // (false at the latest when no lane is left)
     }
@@ -565,11 +575,23 @@ DEV void travTrip(const KParams& P, TravState& s, Trav& t, uint32_t* stk) {
     if (entryIsLeaf(s.e)) travLeaf<INSTR, RIS>(P, s, t, stk);
 }
 
-template <bool INSTR, bool RIS = false>
-DEV void traverse3(const KParams& P, const v3 wpos, const v3 wdir, const v3 winv, uint32_t* stk, Trav& t) {
+template <bool INSTR, bool RIS = false, bool TOP = false>
+DEV void traverse3(const KParams& P, const v3 wpos, const v3 wdir, const v3 winv, uint32_t* stk, Trav& t, const float4* topLds = nullptr) {
     TravState s;
-    travBegin<INSTR, RIS>(P, s, t, wpos, wdir, winv, stk);
-    while (__builtin_amdgcn_ballot_w64(s.e != ENTRY_DEAD) != 0) travTrip<INSTR, RIS>(P, s, t, stk);
+    travBegin<INSTR, RIS, TOP>(P, s, t, wpos, wdir, winv, stk);
+    s.topLds = topLds;
+    while (__builtin_amdgcn_ballot_w64(s.e != ENTRY_DEAD) != 0) travTrip<INSTR, RIS, TOP>(P, s, t, stk);
+}
+// TOP kernels: the wave's own copy of the table of top nodes, behind the stacks of the workgroup's waves in dynamic LDS
+// (P.topCount records of 64 bytes per wave).  Wave-private, so a wave-level fence is all the ordering it needs.
+DEV const float4* loadTopTable(const KParams& P, uint32_t* lds) {
+    const uint32_t waves = blockDim.x >> 6, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    float4* dst = (float4*)(lds + (size_t)waves * P.stackDepth * 64) + (size_t)wave * P.topCount * 4;
+    for (int i = (int)lane; i < P.topCount * 4; i += 64) dst[i] = P.top[i];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    return dst;
 }
 
 // Shading data of a traversal result, as TraverseSceneBVH leaves it in hitInfo (RS:248-258).
@@ -935,9 +957,10 @@ DEV bool temporalMerge(const KParams& P, const Pixel& px, Reservoir& thisFrame) 
 }
 // TEMP: the launch also makes TemporalReuse's merge (RS:586-641) for its pixel, on the reservoir it has just produced
 // (or, for a pixel whose depth holds a hit that its HitInfo does not, on the stored one), and stores the result once.
-template <bool INSTR, bool TEMP = false>
+template <bool INSTR, bool TEMP = false, bool TOP = false>
 __global__ __launch_bounds__(256, RT_MIN_WAVES) void k_candidates(const KParams P) {
     extern __shared__ uint32_t lds[];
+    const float4* topLds = TOP ? loadTopTable(P, lds) : nullptr;
     const Pixel px = pixelOfThread(P);
     uint32_t rays = 0;
     Trav t;
@@ -990,7 +1013,7 @@ __global__ __launch_bounds__(256, RT_MIN_WAVES) void k_candidates(const KParams 
                 v2 wb = GenerateCandidateWeight(P, sqrDst, hitAngleDot, hitInfo.incomingDir, dir, hitInfo.normal,
                                                 metallicity, roughness, lightObject.brightness);
                 if (P.kwVisReuse) {  // RS:422-430
-                    TRAVERSE<INSTR>(P, hitInfo.hitPoint, dir, rcp3(dir), laneStack(lds, P.stackDepth), t);
+                    TRAVERSE<INSTR, false, TOP>(P, hitInfo.hitPoint, dir, rcp3(dir), laneStack(lds, P.stackDepth), t, topLds);
                     rays = 1;
                     int shadowMat = t.obj >= 0 ? P.objs[t.obj].materialIndex : 0;
                     if (loadMaterial(P, shadowMat).brightness == 0) wb.x = 0;
@@ -1242,12 +1265,13 @@ DEV v3 SampleEnvironmentMap(const KParams& P, v3 dir) {  // RS:102-117
 // depth buffer holds a hit - and takes the reservoir it shades with from that copy.  ACC: it also makes
 // AccumulateFrames' running average (PostProcessor.compute:10-19) of the colour it stores.  Both are what the separate
 // kernels would do to this pixel, in the same order.
-template <bool INSTR, bool XFER = false, bool ACC = false>
+template <bool INSTR, bool XFER = false, bool ACC = false, bool TOP = false>
 #ifndef RT_TRACE_WAVES
 #define RT_TRACE_WAVES 4   // (3: 133 registers and no spilled value at all, 269 against 243 us)
 #endif
 __global__ __launch_bounds__(256, RT_TRACE_WAVES) void k_trace_rays(const KParams P) {
     extern __shared__ uint32_t lds[];
+    const float4* topLds = TOP ? loadTopTable(P, lds) : nullptr;
     const Pixel px = pixelOfThread(P);
     uint32_t rays = 0, pops = 0, bvc = 0, objv = 0, trii = 0, tric = 0, iters = 0, steps = 0;
     Trav acc;
@@ -1325,7 +1349,7 @@ __global__ __launch_bounds__(256, RT_TRACE_WAVES) void k_trace_rays(const KParam
                 if (bounceCount != P.MaxBounceCount) {
                     Trav t;
                     travResetWaveCounts<INSTR>(t);
-                    TRAVERSE<INSTR>(P, rpos, rdir, rinv, laneStack(lds, P.stackDepth), t);
+                    TRAVERSE<INSTR, false, TOP>(P, rpos, rdir, rinv, laneStack(lds, P.stackDepth), t, topLds);
                     rays++;
                     steps += t.steps;
                     if (INSTR) {
@@ -1448,6 +1472,25 @@ __global__ void k_obj_root_entries(const rt_bv* BVs, int64_t nBVs, const rt_scen
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= nObjs) return;
     out[i] = entryOf(BVs, nBVs, (int64_t)(uint32_t)objs[i].bvStartIndex);
+}
+// The table of top nodes (ENTRY_TOP): slot s is the wide record of node plan.node[s], with the entries of those children
+// that have a slot of their own replaced by that slot; and the objects' root entries with the same replacement.
+__global__ void k_build_top(const float4* wide, TopPlan plan, float4* top) {
+    const int s = (int)threadIdx.x;
+    if (s >= plan.n) return;
+    const float4* rec = wide + (size_t)plan.node[s] * 4;
+    float4 q3 = rec[3];
+    if (plan.slotA[s] >= 0) q3.x = __uint_as_float(ENTRY_TOP | (uint32_t)plan.slotA[s]);
+    if (plan.slotB[s] >= 0) q3.y = __uint_as_float(ENTRY_TOP | (uint32_t)plan.slotB[s]);
+    top[s * 4 + 0] = rec[0]; top[s * 4 + 1] = rec[1]; top[s * 4 + 2] = rec[2]; top[s * 4 + 3] = q3;
+}
+__global__ void k_obj_root_entries_top(const uint32_t* objRoot, const rt_scene_object* objs, int64_t nObjs, TopPlan plan, uint32_t* out) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nObjs) return;
+    uint32_t e = objRoot[i];
+    if (e < ENTRY_LEAF_INDIRECT)   // an internal root: its BV index may have a slot
+        for (int s = 0; s < plan.n; s++) if (plan.node[s] == e) { e = ENTRY_TOP | (uint32_t)s; break; }
+    out[i] = e;
 }
 __global__ void k_bake_tris(const rt_triangle* tris, int64_t nTris, const rt_vertex* verts, int64_t nVerts, float4* out) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;

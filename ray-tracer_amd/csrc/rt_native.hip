@@ -238,6 +238,10 @@ struct rt_ctx_s {
         float4* wide = nullptr; size_t wideBytes = 0;
         float4* btri = nullptr; size_t btriBytes = 0;
         uint32_t* objRoot = nullptr; size_t objRootBytes = 0;
+        float4* top = nullptr; size_t topBytes = 0;              // table of top nodes (ENTRY_TOP), when asked for
+        uint32_t* objRootTop = nullptr; size_t objRootTopBytes = 0;
+        int topCount = 0;
+        uint32_t sceneRootEntryTop = 0;
         uint64_t vBVs = 0, vTris = 0, vVerts = 0, vObjs = 0;
         const void *pBVs = nullptr, *pTris = nullptr, *pVerts = nullptr, *pObjs = nullptr;
         uint32_t sceneStart = 0xffffffffu;
@@ -247,6 +251,8 @@ struct rt_ctx_s {
         bool valid = false;
         uint64_t lastUse = 0;
     };
+    bool launchingHeld = false;   // inside launchHeld (the launches that may use the table of top nodes): for the trace
+    int topNodes = 0;   // tuning top_nodes_lds: slots of the table of top nodes the merged ray kernels keep in LDS (0: none)
     static constexpr size_t MAX_PREPS = 4;
     std::vector<Prep> preps;
     uint64_t prepClock = 0;
@@ -431,6 +437,7 @@ void traceLaunch(rt_ctx ctx, hipStream_t stream, int ik, const KParams* Pp, bool
             case IK_CANDIDATES:
                 t.r(P.hit.p0); t.w(P.cand.q);
                 if (merged) { t.r(P.depth.r); t.w(P.temporal.p0); t.r(P.hitA.rgba); t.r(P.hitB.rgba); }
+                if (ctx->launchingHeld && P.topCount > 0) t.r(P.top);   // (the variant that keeps the top nodes in LDS)
                 break;
             case IK_TEMPORAL:
                 t.w(P.cand.q); t.w(P.temporal.p0); t.r(P.depth.r); t.r(P.hitA.rgba); t.r(P.hitB.rgba);
@@ -450,6 +457,7 @@ void traceLaunch(rt_ctx ctx, hipStream_t stream, int ik, const KParams* Pp, bool
                 if (merged) { t.r(P.candB.q); t.r(P.depth.r); }
                 if (acc) t.w(P.accumulated.rgba);
                 if (P.kwWeightRecalc) t.w(P.temporal.p0);
+                if (ctx->launchingHeld && P.topCount > 0) t.r(P.top);
                 break;
             case IK_ACCUMULATE:
                 t.r(P.result.rgba); t.w(P.accumulated.rgba);
@@ -935,6 +943,60 @@ int prepareScene(rt_shader sh, int kernel, KParams& P, bool ris = false) {
                 else pr.sceneRootEntry = ENTRY_LEAF_INDIRECT | sceneStart;
             } else pr.sceneRootEntry = sceneStart;
         }
+        // The table of top nodes, when asked for: breadth first from the scene root, through the scene-level leaves into
+        // the objects' mesh BVHs (each mesh once), internal nodes only, until the table is full.
+        pr.topCount = 0;
+        pr.sceneRootEntryTop = pr.sceneRootEntry;
+        if (ctx->topNodes > 0 && !ris) {
+            TopPlan plan;
+            memset(&plan, 0, sizeof plan);
+            const int want = ctx->topNodes > TOP_MAX ? TOP_MAX : ctx->topNodes;
+            struct Item { uint32_t node; bool sceneLevel; int parentSlot; int side; };
+            std::vector<Item> queue;
+            std::map<uint32_t, int> slotOfRoot;   // mesh roots already queued
+            auto internal = [&](uint32_t n) { return n < nNodes && bvs[n].indexA < 0; };
+            if (internal(sceneStart)) queue.push_back({sceneStart, true, -1, 0});
+            else if (bvs[sceneStart].indexA >= 0) {   // the scene root is a leaf: straight into its objects
+                const int64_t start = bvs[sceneStart].indexA, count = bvs[sceneStart].indexB < 0 ? -(int64_t)bvs[sceneStart].indexB : bvs[sceneStart].indexB;
+                for (int64_t k = start; k < start + count && k < (int64_t)objs.size(); k++) {
+                    const uint32_t r = (uint32_t)objs[(size_t)k].bvStartIndex;
+                    if (internal(r) && slotOfRoot.emplace(r, 0).second) queue.push_back({r, false, -1, 0});
+                }
+            }
+            for (size_t head = 0; head < queue.size() && plan.n < want; head++) {
+                const Item it = queue[head];
+                const int slot = plan.n++;
+                plan.node[slot] = it.node;
+                plan.slotA[slot] = plan.slotB[slot] = -1;
+                if (it.parentSlot >= 0) (it.side == 0 ? plan.slotA : plan.slotB)[it.parentSlot] = (int16_t)slot;
+                const Link& bv = bvs[it.node];
+                const uint32_t child[2] = {(uint32_t)(-(int64_t)bv.indexA), (uint32_t)(bv.indexB < 0 ? -(int64_t)bv.indexB : (int64_t)bv.indexB)};
+                for (int side = 0; side < 2; side++) {
+                    const uint32_t c = child[side];
+                    if (c >= nNodes) continue;
+                    if (bvs[c].indexA < 0) queue.push_back({c, it.sceneLevel, slot, side});
+                    else if (it.sceneLevel) {   // a scene-level leaf: the mesh roots of its objects join the queue (no parent record names them)
+                        const int64_t start = bvs[c].indexA, count = bvs[c].indexB < 0 ? -(int64_t)bvs[c].indexB : bvs[c].indexB;
+                        for (int64_t k = start; k < start + count && k < (int64_t)objs.size(); k++) {
+                            const uint32_t r = (uint32_t)objs[(size_t)k].bvStartIndex;
+                            if (internal(r) && slotOfRoot.emplace(r, 0).second) queue.push_back({r, false, -1, 0});
+                        }
+                    }
+                }
+            }
+            // (children queued after the table filled up have no slot: their parents keep the BV index, slotA/B stay -1;
+            // a child's slot was set when the child itself was taken off the queue)
+            if (plan.n > 0) {
+                if ((rc = ensure((void**)&pr.top, &pr.topBytes, (size_t)TOP_MAX * 64))) return rc;
+                if ((rc = ensure((void**)&pr.objRootTop, &pr.objRootTopBytes, (size_t)bObjs->count * 4))) return rc;
+                hipLaunchKernelGGL(k_build_top, dim3(1), dim3(TOP_MAX), 0, S(ctx), (const float4*)pr.wide, plan, pr.top);
+                hipLaunchKernelGGL(k_obj_root_entries_top, dim3((unsigned)((bObjs->count + 255) / 256)), dim3(256), 0, S(ctx),
+                                   (const uint32_t*)pr.objRoot, (const rt_scene_object*)bObjs->dev, bObjs->count, plan, pr.objRootTop);
+                LAUNCH_TRY(ctx, "build_top / obj_root_entries_top");
+                pr.topCount = plan.n;
+                if (plan.node[0] == sceneStart && internal(sceneStart)) pr.sceneRootEntryTop = ENTRY_TOP | 0u;
+            }
+        }
         pr.vBVs = bBVs->version; pr.vTris = bTris->version; pr.vVerts = bVerts->version; pr.vObjs = bObjs->version;
         pr.pBVs = bBVs->dev; pr.pTris = bTris->dev; pr.pVerts = bVerts->dev; pr.pObjs = bObjs->dev;
         pr.sceneStart = sceneStart;
@@ -954,6 +1016,7 @@ int prepareScene(rt_shader sh, int kernel, KParams& P, bool ris = false) {
     }
     P.sceneRootEntry = pr.sceneRootEntry;
     P.stackDepth = pr.stackDepth;
+    P.top = pr.top; P.topCount = pr.topCount; P.objRootEntryTop = pr.objRootTop; P.sceneRootEntryTop = pr.sceneRootEntryTop;
     return RT_OK;
 }
 
@@ -1484,8 +1547,14 @@ void launchHeld(rt_ctx ctx, bool acc) {
     } else if (h.kind == 3) {
         if (acc && !h.temporalWaited) waitShared(ctx, rt_ctx_s::SH_TEMPORAL, st);
         {
+            size_t topLds = (size_t)rayBlock(ctx, h.blocks).x / 64 * h.P.topCount * 64;   // a copy of the table per wave
+            if (rayLds(ctx, h.blocks, h.ldsBytes) + topLds > 65536) { h.P.topCount = 0; topLds = 0; }   // (no room beside the stacks)
+            ctx->launchingHeld = true;
             LaunchScope ls(ctx, IK_CANDIDATES, &h.P, st, acc);
-            if (acc) hipLaunchKernelGGL((k_candidates<false, true>), rayGrid(ctx, h.blocks), rayBlock(ctx, h.blocks), rayLds(ctx, h.blocks, h.ldsBytes), st, h.P);
+            ctx->launchingHeld = false;
+            if (h.P.topCount > 0 && acc) hipLaunchKernelGGL((k_candidates<false, true, true>), rayGrid(ctx, h.blocks), rayBlock(ctx, h.blocks), rayLds(ctx, h.blocks, h.ldsBytes) + topLds, st, h.P);
+            else if (h.P.topCount > 0) hipLaunchKernelGGL((k_candidates<false, false, true>), rayGrid(ctx, h.blocks), rayBlock(ctx, h.blocks), rayLds(ctx, h.blocks, h.ldsBytes) + topLds, st, h.P);
+            else if (acc) hipLaunchKernelGGL((k_candidates<false, true>), rayGrid(ctx, h.blocks), rayBlock(ctx, h.blocks), rayLds(ctx, h.blocks, h.ldsBytes), st, h.P);
             else hipLaunchKernelGGL((k_candidates<false, false>), rayGrid(ctx, h.blocks), rayBlock(ctx, h.blocks), rayLds(ctx, h.blocks, h.ldsBytes), st, h.P);
         }
         if (acc) markShared(ctx, rt_ctx_s::SH_TEMPORAL, st);
@@ -1502,8 +1571,16 @@ void launchHeld(rt_ctx ctx, bool acc) {
         waitShared(ctx, rt_ctx_s::SH_RESULT, st);
         if (h.P.kwWeightRecalc) waitShared(ctx, rt_ctx_s::SH_TEMPORAL, st);   // (RS:645-657 writes into TemporalFrameBuffer)
         {
+            size_t topLds = (size_t)rayBlock(ctx, h.blocks).x / 64 * h.P.topCount * 64;
+            if (rayLds(ctx, h.blocks, h.ldsBytes) + topLds > 65536) { h.P.topCount = 0; topLds = 0; }
+            ctx->launchingHeld = true;
             LaunchScope ls(ctx, IK_TRACE_RAYS, &h.P, st, h.withTransfer, acc);
-            if (h.withTransfer && acc) hipLaunchKernelGGL((k_trace_rays<false, true, true>), rayGrid(ctx, h.blocks), rayBlock(ctx, h.blocks), rayLds(ctx, h.blocks, h.ldsBytes), st, h.P);
+            ctx->launchingHeld = false;
+            if (h.P.topCount > 0 && h.withTransfer && acc) hipLaunchKernelGGL((k_trace_rays<false, true, true, true>), rayGrid(ctx, h.blocks), rayBlock(ctx, h.blocks), rayLds(ctx, h.blocks, h.ldsBytes) + topLds, st, h.P);
+            else if (h.P.topCount > 0 && h.withTransfer) hipLaunchKernelGGL((k_trace_rays<false, true, false, true>), rayGrid(ctx, h.blocks), rayBlock(ctx, h.blocks), rayLds(ctx, h.blocks, h.ldsBytes) + topLds, st, h.P);
+            else if (h.P.topCount > 0 && acc) hipLaunchKernelGGL((k_trace_rays<false, false, true, true>), rayGrid(ctx, h.blocks), rayBlock(ctx, h.blocks), rayLds(ctx, h.blocks, h.ldsBytes) + topLds, st, h.P);
+            else if (h.P.topCount > 0) hipLaunchKernelGGL((k_trace_rays<false, false, false, true>), rayGrid(ctx, h.blocks), rayBlock(ctx, h.blocks), rayLds(ctx, h.blocks, h.ldsBytes) + topLds, st, h.P);
+            else if (h.withTransfer && acc) hipLaunchKernelGGL((k_trace_rays<false, true, true>), rayGrid(ctx, h.blocks), rayBlock(ctx, h.blocks), rayLds(ctx, h.blocks, h.ldsBytes), st, h.P);
             else if (h.withTransfer) hipLaunchKernelGGL((k_trace_rays<false, true, false>), rayGrid(ctx, h.blocks), rayBlock(ctx, h.blocks), rayLds(ctx, h.blocks, h.ldsBytes), st, h.P);
             else if (acc) hipLaunchKernelGGL((k_trace_rays<false, false, true>), rayGrid(ctx, h.blocks), rayBlock(ctx, h.blocks), rayLds(ctx, h.blocks, h.ldsBytes), st, h.P);
             else hipLaunchKernelGGL((k_trace_rays<false, false, false>), rayGrid(ctx, h.blocks), rayBlock(ctx, h.blocks), rayLds(ctx, h.blocks, h.ldsBytes), st, h.P);
@@ -2026,6 +2103,8 @@ void rt_destroy(rt_ctx ctx) {
         if (pr.wide) e = devFree(ctx, pr.wide);
         if (pr.btri) e = devFree(ctx, pr.btri);
         if (pr.objRoot) e = devFree(ctx, pr.objRoot);
+        if (pr.top) e = devFree(ctx, pr.top);
+        if (pr.objRootTop) e = devFree(ctx, pr.objRootTop);
     }
     ctx->pool.capBytes = 0;
     devPoolTrim(ctx, 0);
@@ -2162,6 +2241,13 @@ int rt_set_tuning(rt_ctx ctx, const char* name, int value) {
         HIP_TRY(ctx, hipStreamSynchronize(S(ctx)));
         freeBlockMaps(ctx);
         ctx->regionBlocks[!strcmp(name, "region_blocks_reuse") ? 0 : !strcmp(name, "region_blocks_primary") ? 1 : 2] = value;
+    }
+    else if (!strcmp(name, "top_nodes_lds")) {   // the prepared scenes are rebuilt with or without the table at their next use
+        if (value < 0 || value > TOP_MAX) return fail(ctx, RT_ERR_INVALID_ARG, "top_nodes_lds must be 0 to %d", TOP_MAX);
+        useMainStream(ctx);
+        HIP_TRY(ctx, hipStreamSynchronize(S(ctx)));
+        ctx->topNodes = value;
+        for (auto& pr : ctx->preps) pr.valid = false;
     }
     else if (!strcmp(name, "device_pool_mb")) {   // released device memory kept for reuse at most; what is kept beyond it is freed now
         if (value < 0) return fail(ctx, RT_ERR_INVALID_ARG, "device_pool_mb must not be negative");
@@ -2498,6 +2584,8 @@ void rt_buffer_release(rt_buffer b) {
         if (pr.wide) e = devFree(ctx, pr.wide);
         if (pr.btri) e = devFree(ctx, pr.btri);
         if (pr.objRoot) e = devFree(ctx, pr.objRoot);
+        if (pr.top) e = devFree(ctx, pr.top);
+        if (pr.objRootTop) e = devFree(ctx, pr.objRootTop);
         pr = rt_ctx_s::Prep();
     }
     if (b->tag) dropCopies(b);
