@@ -7,7 +7,7 @@ for lib in "$@"; do
   python - <<PY
 import json
 d=json.load(open("gpurun_out/ab_lib.json"))
-print("$lib", round(d["ms_per_step"],4), round(d["value"]), {k:round(v["avg_ms"]*1e3) for k,v in d["kernels"].items()})
+print("$lib", round(d["ms_per_step"],4), round(d["value"]), {k:(round(v["avg_ms"]*1e3), round(v.get("isolated_avg_ms", 0)*1e3, 1)) for k,v in d["kernels"].items()})
 PY
 done
 cp /tmp/librtnative.keep ray-tracer_amd/librtnative.so
