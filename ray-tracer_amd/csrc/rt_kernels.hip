@@ -1465,6 +1465,32 @@ __global__ void k_extract_links(const rt_bv* BVs, int64_t nBVs, int2* links) {
     if (n >= nBVs) return;
     links[n] = make_int2(BVs[n].indexA, BVs[n].indexB);
 }
+// A digest of links[0, n) that depends on every word and its position: two sums of differently mixed (index, link)
+// pairs, added into out[0] and out[1] (zeroed by the caller).  A reload uploads the same mesh BVHs again; equal
+// digests of the part below the scene BVH let the host keep what it found out about them (prepareScene).
+DEV unsigned long long mix64(unsigned long long x) {
+    x ^= x >> 30; x *= 0xbf58476d1ce4e5b9ull; x ^= x >> 27; x *= 0x94d049bb133111ebull; x ^= x >> 31;
+    return x;
+}
+DEV unsigned long long waveSum64(unsigned long long v) {
+    for (int off = 32; off > 0; off >>= 1) {
+        const uint32_t lo = __shfl_xor((uint32_t)v, off, 64), hi = __shfl_xor((uint32_t)(v >> 32), off, 64);
+        v += ((unsigned long long)hi << 32) | lo;
+    }
+    return v;
+}
+__global__ __launch_bounds__(256) void k_hash_links(const int2* links, int64_t n, unsigned long long* out) {
+    unsigned long long h0 = 0, h1 = 0;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const int2 l = links[i];
+        const unsigned long long w = ((unsigned long long)(uint32_t)l.x << 32) | (uint32_t)l.y;
+        h0 += mix64(w ^ mix64((unsigned long long)i));
+        h1 += mix64((w + 0x9e3779b97f4a7c15ull) ^ mix64((unsigned long long)i * 0xd6e8feb86659fd93ull + 1));
+    }
+    h0 = waveSum64(h0);
+    h1 = waveSum64(h1);
+    if ((threadIdx.x & 63) == 0) { atomicAdd(out, h0); atomicAdd(out + 1, h1); }
+}
 __global__ void k_check_tri_indices(const rt_triangle* tris, int64_t nTris, int64_t nVerts, uint32_t* flag) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= nTris) return;

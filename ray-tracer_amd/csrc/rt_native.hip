@@ -64,6 +64,8 @@ struct Copies {
     int n = 0;
 };
 
+struct Link { int32_t indexA, indexB; };   // the two index words of a BV node
+
 struct rt_ctx_s {
     int device = 0;
     // The dispatch stream.  Every use goes through S(ctx) or SK(ctx), which first launch a held-back dispatch (see Deferred).
@@ -252,6 +254,18 @@ struct rt_ctx_s {
         uint64_t lastUse = 0;
     };
     bool launchingHeld = false;   // inside launchHeld (the launches that may use the table of top nodes): for the trace
+    // What the last full validation of a scene found out about the part of BVs BELOW its scene BVH (the mesh BVHs): a
+    // reload uploads that part again unchanged (ObjectHelper.ConstructScene keeps the meshes and appends or replaces
+    // the scene BVH), and a digest of its link words, taken on the device, is enough to know.  One per project.
+    struct MeshInfo { int depth; uint32_t maxNode; int64_t leafEnd; };
+    struct Validated {
+        bool valid = false;
+        size_t nPrefix = 0;                        // nodes [0, nPrefix) lie below every scene-level node of the validated scene
+        unsigned long long digest[2] = {0, 0};     // of their link words
+        std::vector<Link> links;                   // host copy of the link words of the BVs last prepared (its first nPrefix are what counts)
+        std::map<uint32_t, MeshInfo> meshes;       // the mesh BVHs validated together, by root: depth, highest node, end of the highest leaf range
+    } validated[2];
+    bool reuseValidation = true;   // tuning reuse_validation
     int topNodes = 0;   // tuning top_nodes_lds: slots of the table of top nodes the merged ray kernels keep in LDS (0: none)
     static constexpr size_t MAX_PREPS = 4;
     std::vector<Prep> preps;
@@ -770,8 +784,11 @@ const int MAX_TREE_DEPTH = 96;  // deepest BVH (scene levels + mesh levels) the 
 // Depth (in nodes, root = 1) of the subtree at `root`; -1 on an index out of range, a cycle or excessive depth.
 // Leaves are checked against `nLeafTargets` (triangles or scene objects).  `links` = (indexA, indexB) per node; `seen`
 // is shared by the threads that check the meshes of one scene (a node two of them reach is a shared subtree).
-struct Link { int32_t indexA, indexB; };
-int subtreeDepth(const std::vector<Link>& bvs, uint32_t root, int64_t nLeafTargets, std::atomic<uint8_t>* seen, std::string& why) {
+// `ext`: receives the lowest and highest node visited and the end of the highest leaf range.  `seenBase`: the walk is
+// expected to stay at or above this node (seen[0] belongs to it); -2 when it does not.
+struct Extent { uint32_t minNode = 0xffffffffu, maxNode = 0; int64_t leafEnd = 0; };
+int subtreeDepth(const std::vector<Link>& bvs, uint32_t root, int64_t nLeafTargets, std::atomic<uint8_t>* seen, std::string& why, Extent* ext = nullptr,
+                 size_t seenBase = 0) {
     struct Item { uint32_t node; int depth; };
     std::vector<Item> st;
     st.push_back({root, 1});
@@ -781,12 +798,15 @@ int subtreeDepth(const std::vector<Link>& bvs, uint32_t root, int64_t nLeafTarge
         st.pop_back();
         if (it.node >= bvs.size()) { why = "BVH child index out of range"; return -1; }
         if (it.depth > MAX_TREE_DEPTH) { why = "BVH deeper than the supported maximum"; return -1; }
-        if (seen[it.node].exchange(2, std::memory_order_relaxed) == 2) { why = "BVH node reachable twice (cycle or shared subtree)"; return -1; }
+        if (it.node < seenBase) { why = "the walk leaves the part it was confined to"; return -2; }
+        if (seen[it.node - seenBase].exchange(2, std::memory_order_relaxed) == 2) { why = "BVH node reachable twice (cycle or shared subtree)"; return -1; }
+        if (ext) { if (it.node < ext->minNode) ext->minNode = it.node; if (it.node > ext->maxNode) ext->maxNode = it.node; }
         if (it.depth > maxDepth) maxDepth = it.depth;
         const Link& bv = bvs[it.node];
         if (bv.indexA >= 0) {
             int64_t start = bv.indexA, count = bv.indexB < 0 ? -(int64_t)bv.indexB : bv.indexB;
             if (start + count > nLeafTargets) { why = "BVH leaf range exceeds its component buffer"; return -1; }
+            if (ext && start + count > ext->leafEnd) ext->leafEnd = start + count;
         } else {
             int64_t a = -(int64_t)bv.indexA, b = bv.indexB < 0 ? -(int64_t)bv.indexB : bv.indexB;
             st.push_back({(uint32_t)a, it.depth + 1});
@@ -845,66 +865,123 @@ int prepareScene(rt_shader sh, int kernel, KParams& P, bool ris = false) {
         // What the host needs of the scene: the nodes' two index words (a quarter of the node array, extracted on the
         // device) and the scene objects.  Whether the triangles' vertex indices are in range is decided on the device.
         const size_t nNodes = (size_t)bBVs->count;
-        std::vector<Link> bvs(nNodes);
+        std::vector<Link> bvs;
         std::vector<rt_scene_object> objs((size_t)bObjs->count);
         // the kernels address the 64-byte node and triangle records with 32-bit byte offsets
         if (nNodes >= ((size_t)1 << 26)) return fail(ctx, RT_ERR_LIMIT, "too many BVH nodes: %zu, the limit is 2^26 - 1", nNodes);
         if ((uint64_t)bTris->count >= ((uint64_t)1 << 26)) return fail(ctx, RT_ERR_LIMIT, "too many triangles: %lld, the limit is 2^26 - 1", (long long)bTris->count);
         if (sceneStart >= nNodes) return fail(ctx, RT_ERR_BAD_SCENE, "SceneBVHStartIndex %u is outside the BVs buffer", sceneStart);
+        // A reload uploads the mesh BVHs it had before and a new scene BVH above them.  If the link words of the nodes
+        // below the last validated scene BVH have the digest they had then (taken on the device: no read-back), what
+        // that validation found out about the meshes still holds, and only the nodes above are read back and walked.
+        rt_ctx_s::Validated& known = ctx->validated[ris ? 1 : 0];
+        const size_t knownPrefix = known.nPrefix;
+        bool prefixKnown = false;
+        struct Scratch { rt_ctx ctx; void* p = nullptr; ~Scratch() { if (p) { hipError_t e = devFree(ctx, p); (void)e; } } } scratch{ctx};
+        HIP_TRY(ctx, devAlloc(ctx, &scratch.p, nNodes * sizeof(Link) + 32));   // links, one flag word, two digest words
+        uint32_t* flagDev = (uint32_t*)((char*)scratch.p + nNodes * sizeof(Link));
+        unsigned long long* digestDev = (unsigned long long*)((char*)flagDev + 8);
         {
-            void* scratchDev = nullptr;   // links, then one flag word
-            HIP_TRY(ctx, devAlloc(ctx, &scratchDev, nNodes * sizeof(Link) + 16));
-            uint32_t* flagDev = (uint32_t*)((char*)scratchDev + nNodes * sizeof(Link));
             uint32_t flag = 0;
-            hipError_t e = hipMemsetAsync(flagDev, 0, 4, S(ctx));
-            hipLaunchKernelGGL(k_extract_links, dim3((unsigned)((nNodes + 255) / 256)), dim3(256), 0, S(ctx), (const rt_bv*)bBVs->dev, bBVs->count, (int2*)scratchDev);
+            unsigned long long digest[2] = {0, 0};
+            const bool tryPrefix = ctx->reuseValidation && known.valid && knownPrefix > 0 && knownPrefix <= nNodes && known.links.size() >= knownPrefix;
+            hipError_t e = hipMemsetAsync(flagDev, 0, 32, S(ctx));
+            hipLaunchKernelGGL(k_extract_links, dim3((unsigned)((nNodes + 255) / 256)), dim3(256), 0, S(ctx), (const rt_bv*)bBVs->dev, bBVs->count, (int2*)scratch.p);
             if (!ris)
                 hipLaunchKernelGGL(k_check_tri_indices, dim3((unsigned)((bTris->count + 255) / 256)), dim3(256), 0, S(ctx),
                                    (const rt_triangle*)bTris->dev, bTris->count, bVerts->count, flagDev);
+            if (tryPrefix) hipLaunchKernelGGL(k_hash_links, dim3(1024), dim3(256), 0, S(ctx), (const int2*)scratch.p, (int64_t)knownPrefix, digestDev);
             if (e == hipSuccess) e = hipGetLastError();
-            if (e == hipSuccess) e = hipMemcpyAsync(bvs.data(), scratchDev, nNodes * sizeof(Link), hipMemcpyDeviceToHost, S(ctx));
+            if (e == hipSuccess && tryPrefix) e = hipMemcpyAsync(digest, digestDev, 16, hipMemcpyDeviceToHost, S(ctx));
             if (e == hipSuccess) e = hipMemcpyAsync(&flag, flagDev, 4, hipMemcpyDeviceToHost, S(ctx));
             if (e == hipSuccess) e = hipMemcpyAsync(objs.data(), bObjs->dev, objs.size() * sizeof(rt_scene_object), hipMemcpyDeviceToHost, S(ctx));
             if (e == hipSuccess) e = hipStreamSynchronize(S(ctx));
-            hipError_t e2 = devFree(ctx, scratchDev);
-            (void)e2;
+            prefixKnown = tryPrefix && e == hipSuccess && digest[0] == known.digest[0] && digest[1] == known.digest[1];
+            size_t first = 0;
+            if (prefixKnown) { bvs = std::move(known.links); first = knownPrefix; }   // the host's copy of the lower part is still right
+            known.valid = false;   // (until this preparation has succeeded)
+            known.links.clear();
+            if (bvs.capacity() < nNodes) bvs.reserve(nNodes + nNodes / 8 + 1024);   // (room for the scene BVHs later reloads append)
+            bvs.resize(nNodes);
+            if (e == hipSuccess && nNodes > first) {
+                e = hipMemcpyAsync((void*)(bvs.data() + first), (const char*)scratch.p + first * sizeof(Link), (nNodes - first) * sizeof(Link), hipMemcpyDeviceToHost, S(ctx));
+                if (e == hipSuccess) e = hipStreamSynchronize(S(ctx));
+            }
             if (e != hipSuccess) return fail(ctx, RT_ERR_NO_DEVICE, "reading the scene back for validation failed: %s", hipGetErrorString(e));
             if (flag) return fail(ctx, RT_ERR_BAD_SCENE, "a triangle's vertex index is outside the Vertices buffer");
         }
-        std::unique_ptr<std::atomic<uint8_t>[]> seen(new std::atomic<uint8_t>[nNodes]());
-        std::string why;
-        int sceneDepth = subtreeDepth(bvs, sceneStart, bObjs->count, seen.get(), why);
-        if (sceneDepth < 0) return fail(ctx, RT_ERR_BAD_SCENE, "scene BVH (SceneBVHStartIndex %u): %s", sceneStart, why.c_str());
-        // the mesh BVHs, each checked once, on as many threads as the machine offers (at most 16): a 10 M-triangle
-        // scene of distinct meshes has 19 M nodes to walk
         std::vector<int> meshRoots;
         {
-            std::map<int, int> known;
+            std::map<int, int> seenRoots;
             for (const auto& o : objs) {
                 if (o.bvStartIndex < 0) return fail(ctx, RT_ERR_BAD_SCENE, "scene object with negative bvStartIndex");
-                if (known.emplace(o.bvStartIndex, 0).second) meshRoots.push_back(o.bvStartIndex);
+                if (seenRoots.emplace(o.bvStartIndex, 0).second) meshRoots.push_back(o.bvStartIndex);
             }
         }
-        std::vector<int> meshDepths(meshRoots.size(), 0);
-        std::vector<std::string> meshWhy(meshRoots.size());
-        {
-            unsigned nThreads = std::thread::hardware_concurrency();
-            nThreads = nThreads < 1 ? 1 : nThreads > 16 ? 16 : nThreads;
-            if (nThreads > meshRoots.size()) nThreads = (unsigned)meshRoots.size();
-            std::atomic<size_t> next(0);
-            auto work = [&] {
-                for (size_t k; (k = next.fetch_add(1)) < meshRoots.size();)
-                    meshDepths[k] = subtreeDepth(bvs, (uint32_t)meshRoots[k], bTris->count, seen.get(), meshWhy[k]);
-            };
-            std::vector<std::thread> pool;
-            for (unsigned t = 1; t < nThreads; t++) pool.emplace_back(work);
-            work();
-            for (auto& t : pool) t.join();
+        std::string why;
+        int sceneDepth = -1, maxMeshDepth = 0;
+        bool reused = false;
+        if (prefixKnown) {
+            // the scene BVH alone, which must lie above the known part; every mesh an object names must be one of those
+            // validated together last time, lie inside the known part, and find its triangles in the buffer bound now
+            std::unique_ptr<std::atomic<uint8_t>[]> seenAbove(new std::atomic<uint8_t>[nNodes - knownPrefix + 1]());
+            const int d = subtreeDepth(bvs, sceneStart, bObjs->count, seenAbove.get(), why, nullptr, knownPrefix);
+            if (d == -1) return fail(ctx, RT_ERR_BAD_SCENE, "scene BVH (SceneBVHStartIndex %u): %s", sceneStart, why.c_str());
+            bool ok = d >= 0;
+            for (size_t k = 0; ok && k < meshRoots.size(); k++) {
+                const auto it = known.meshes.find((uint32_t)meshRoots[k]);
+                ok = it != known.meshes.end() && (size_t)meshRoots[k] < knownPrefix && it->second.maxNode < knownPrefix && it->second.leafEnd <= bTris->count;
+                if (ok && it->second.depth > maxMeshDepth) maxMeshDepth = it->second.depth;
+            }
+            if (ok) { reused = true; sceneDepth = d; }
+            else maxMeshDepth = 0;
         }
-        int maxMeshDepth = 0;
-        for (size_t k = 0; k < meshRoots.size(); k++) {
-            if (meshDepths[k] < 0) return fail(ctx, RT_ERR_BAD_SCENE, "mesh BVH at %d: %s", meshRoots[k], meshWhy[k].c_str());
-            if (meshDepths[k] > maxMeshDepth) maxMeshDepth = meshDepths[k];
+        if (!reused) {
+            std::unique_ptr<std::atomic<uint8_t>[]> seen(new std::atomic<uint8_t>[nNodes]());
+            Extent sceneExt;
+            sceneDepth = subtreeDepth(bvs, sceneStart, bObjs->count, seen.get(), why, &sceneExt);
+            if (sceneDepth < 0) return fail(ctx, RT_ERR_BAD_SCENE, "scene BVH (SceneBVHStartIndex %u): %s", sceneStart, why.c_str());
+            // the mesh BVHs, each checked once, on as many threads as the machine offers (at most 16): a 10 M-triangle
+            // scene of distinct meshes has 19 M nodes to walk
+            std::vector<int> meshDepths(meshRoots.size(), 0);
+            std::vector<std::string> meshWhy(meshRoots.size());
+            std::vector<Extent> meshExt(meshRoots.size());
+            {
+                unsigned nThreads = std::thread::hardware_concurrency();
+                nThreads = nThreads < 1 ? 1 : nThreads > 16 ? 16 : nThreads;
+                if (nThreads > meshRoots.size()) nThreads = (unsigned)meshRoots.size();
+                std::atomic<size_t> next(0);
+                auto work = [&] {
+                    for (size_t k; (k = next.fetch_add(1)) < meshRoots.size();)
+                        meshDepths[k] = subtreeDepth(bvs, (uint32_t)meshRoots[k], bTris->count, seen.get(), meshWhy[k], &meshExt[k]);
+                };
+                std::vector<std::thread> pool;
+                for (unsigned t = 1; t < nThreads; t++) pool.emplace_back(work);
+                work();
+                for (auto& t : pool) t.join();
+            }
+            for (size_t k = 0; k < meshRoots.size(); k++) {
+                if (meshDepths[k] < 0) return fail(ctx, RT_ERR_BAD_SCENE, "mesh BVH at %d: %s", meshRoots[k], meshWhy[k].c_str());
+                if (meshDepths[k] > maxMeshDepth) maxMeshDepth = meshDepths[k];
+            }
+            // what the next preparation may rely on: the meshes that lie wholly below the scene BVH, and the digest of that part
+            known.meshes.clear();
+            known.nPrefix = sceneExt.minNode <= nNodes ? sceneExt.minNode : 0;
+            for (size_t k = 0; k < meshRoots.size(); k++)
+                if (meshExt[k].maxNode < known.nPrefix) known.meshes[(uint32_t)meshRoots[k]] = {meshDepths[k], meshExt[k].maxNode, meshExt[k].leafEnd};
+            known.digest[0] = known.digest[1] = 0;
+            if (known.nPrefix > 0 && !known.meshes.empty()) {
+                hipError_t e = hipMemsetAsync(digestDev, 0, 16, S(ctx));
+                hipLaunchKernelGGL(k_hash_links, dim3(1024), dim3(256), 0, S(ctx), (const int2*)scratch.p, (int64_t)known.nPrefix, digestDev);
+                if (e == hipSuccess) e = hipGetLastError();
+                if (e == hipSuccess) e = hipMemcpyAsync(known.digest, digestDev, 16, hipMemcpyDeviceToHost, S(ctx));
+                if (e == hipSuccess) e = hipStreamSynchronize(S(ctx));
+                if (e != hipSuccess) known.nPrefix = 0;
+            } else known.nPrefix = 0;
+        }
+        if (ctx->tracing) {   // (for tests: which way this preparation went)
+            TraceLaunch t(ctx, ctx->stream0, reused ? "scene_check_reused" : "scene_check_full");
+            ctx->traceOps.push_back(t.op);
         }
         pr.stackDepth = sceneDepth + maxMeshDepth;   // entries stacked on the deepest path (one per internal level) + 2
         // the per-lane stack lives in LDS: 4 waves x 64 lanes x 4 bytes per entry, within the 64 KiB a workgroup may ask for
@@ -1001,6 +1078,7 @@ int prepareScene(rt_shader sh, int kernel, KParams& P, bool ris = false) {
         pr.pBVs = bBVs->dev; pr.pTris = bTris->dev; pr.pVerts = bVerts->dev; pr.pObjs = bObjs->dev;
         pr.sceneStart = sceneStart;
         pr.valid = true;
+        if (known.nPrefix > 0) { known.links = std::move(bvs); known.valid = true; }
     }
     P.wide = pr.wide; P.btri = pr.btri; P.objRootEntry = pr.objRoot;
     P.BVs = (const rt_bv*)bBVs->dev; P.nBVs = bBVs->count;
@@ -2249,6 +2327,7 @@ int rt_set_tuning(rt_ctx ctx, const char* name, int value) {
         ctx->topNodes = value;
         for (auto& pr : ctx->preps) pr.valid = false;
     }
+    else if (!strcmp(name, "reuse_validation")) { ctx->reuseValidation = value != 0; if (!value) { ctx->validated[0] = rt_ctx_s::Validated(); ctx->validated[1] = rt_ctx_s::Validated(); } }
     else if (!strcmp(name, "device_pool_mb")) {   // released device memory kept for reuse at most; what is kept beyond it is freed now
         if (value < 0) return fail(ctx, RT_ERR_INVALID_ARG, "device_pool_mb must not be negative");
         ctx->pool.capBytes = (size_t)value << 20;

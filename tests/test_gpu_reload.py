@@ -259,3 +259,93 @@ def test_reloads_reuse_released_device_memory(pool_mb):
 def test_device_pool_argument_is_checked(gpu_ctx):
     with pytest.raises(rt.NativeError):
         gpu_ctx.set_tuning("device_pool_mb", -1)
+
+
+def _scene_checks(ctx, render):
+    """Names of the scene checks (full: every mesh BVH walked; reused: only the scene BVH) logged while `render` runs."""
+    ctx.trace(True)
+    try:
+        render()
+        ctx.sync()
+    finally:
+        ctx.trace(False)
+    return [l.split()[2] for l in ctx.trace_text().splitlines() if l.startswith("L ") and "scene_check" in l]
+
+
+@pytest.mark.parametrize("reuse", [1, 0])
+def test_reload_keeps_what_is_known_about_unchanged_meshes(reuse):
+    """A reload uploads the mesh BVHs it had before and a new scene BVH above them: the library recognises the lower
+    part of BVs by a digest taken on the device and walks only the scene BVH again (reuse_validation 0: every mesh)."""
+    scene = rt.build_scene_s0(subdivide=False)
+    cfg = h.small_config(96, 64)
+    ctx = rt.RtContext(0)
+    ctx.set_tuning("reuse_validation", reuse)
+    drv = rt.Driver(ctx, cfg, scene)
+    orc = h.OracleRenderer(scene.arrays(), cfg)
+    try:
+        assert _scene_checks(ctx, lambda: (drv.render_frame(), orc.render_frame())) == ["scene_check_full"]
+        assert _scene_checks(ctx, lambda: (drv.render_frame(), orc.render_frame())) == []      # prepared already
+        for k in range(3):
+            scene.set_object_transform(1, (-3.0 + 0.2 * k, -2.0, 12.0), (0.0, 25.0 + 3 * k, 0.0), (12.0, 12.0, 12.0))
+            scene.rebuild()
+            drv.reload(); orc.reload(scene.arrays())
+            got = _scene_checks(ctx, lambda: (drv.render_frame(), orc.render_frame()))
+            assert got == (["scene_check_reused"] if reuse else ["scene_check_full"]), got
+            drv.render_frame(); orc.render_frame()
+            compare(drv, orc, f"after reload {k} (reuse_validation {reuse})")
+    finally:
+        drv.close()
+        ctx.close()
+
+
+def test_a_changed_scene_is_checked_in_full_again(scene_small):
+    """What a reload may rely on is exactly: the same link words below the scene BVH, the scene BVH above them, meshes
+    that were checked together, triangles still in the buffer.  Anything else is walked in full - and refused if bad."""
+    a = scene_small.arrays()
+    cfg = h.small_config(32, 32)
+    ctx = rt.RtContext(0)
+    drv = rt.Driver(ctx, cfg, scene_small)
+    try:
+        assert _scene_checks(ctx, drv.render_frame) == ["scene_check_full"]
+        root = int(a["sceneBVHStartIndex"])
+        mesh_root = int(a["SceneObjects"]["bvStartIndex"].max())
+        assert a["BVs"]["indexA"][mesh_root] < 0 and mesh_root < root
+
+        # the same arrays uploaded again: recognised
+        ctx.set_buffer_data(drv.buffer_handle("BVs"), a["BVs"])
+        assert _scene_checks(ctx, drv.render_frame) == ["scene_check_reused"]
+
+        # a scene BVH that reaches down into a mesh: not the shape a reload has -> full walk, which refuses the shared nodes
+        bad = a["BVs"].copy()
+        bad["indexB"][root] = -(mesh_root + 1)
+        ctx.set_buffer_data(drv.buffer_handle("BVs"), bad)
+        with pytest.raises(rt.NativeError):
+            drv.render_frame()
+        ctx.set_buffer_data(drv.buffer_handle("BVs"), a["BVs"])
+        assert _scene_checks(ctx, drv.render_frame) == ["scene_check_full"]     # (a failed preparation leaves nothing to rely on)
+
+        # a mesh part that changed (here: damaged) is never taken for the known one
+        bad = a["BVs"].copy()
+        bad["indexB"][mesh_root] = bad["indexA"][mesh_root]
+        ctx.set_buffer_data(drv.buffer_handle("BVs"), bad)
+        with pytest.raises(rt.NativeError, match="reachable twice"):
+            drv.render_frame()
+        ctx.set_buffer_data(drv.buffer_handle("BVs"), a["BVs"])
+        assert _scene_checks(ctx, drv.render_frame) == ["scene_check_full"]
+
+        # an object that names a node inside a checked mesh as its root: that is not one of the meshes checked together
+        objs = a["SceneObjects"].copy()
+        child = -int(a["BVs"]["indexA"][mesh_root])
+        assert a["BVs"]["indexA"][child] < 0
+        k = int(np.argmax(objs["bvStartIndex"]))
+        objs["bvStartIndex"][k] = child
+        ctx.set_buffer_data(drv.buffer_handle("SceneObjects"), objs)
+        assert _scene_checks(ctx, drv.render_frame) == ["scene_check_full"]     # (valid: half of the mesh as a mesh of its own)
+        ctx.set_buffer_data(drv.buffer_handle("SceneObjects"), a["SceneObjects"])
+        assert _scene_checks(ctx, drv.render_frame) == ["scene_check_full"]     # (the whole mesh was not among those last checked)
+        ctx.set_buffer_data(drv.buffer_handle("BVs"), a["BVs"])
+        assert _scene_checks(ctx, drv.render_frame) == ["scene_check_reused"]
+        ctx.sync()
+    finally:
+        drv.close()
+        ctx.close()
