@@ -131,7 +131,13 @@ def test_ris_project_reload(gpu_ctx):
         drv.reload()
         orc.reload(scene.arrays())
         for f in range(2, 5):
+            if f == 2:   # the frame that reloads: the mesh BVHs below the replaced scene BVH are recognised, not walked again
+                gpu_ctx.trace(True)
             drv.render_frame(); orc.render_frame()
+            if f == 2:
+                gpu_ctx.sync()
+                gpu_ctx.trace(False)
+                assert [l.split()[2] for l in gpu_ctx.trace_text().splitlines() if "scene_check" in l] == ["scene_check_reused"]
             for k in ("HitInfos", "Candidates"):
                 assert np.array_equal(h.bits(drv.buffer(k)), h.bits(orc.buf[k])), f"frame {f}: {k}"
             for k in ("Result", "AccumulatedResult", "DebugOverlay", "RayHitPoints"):

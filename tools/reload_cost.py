@@ -20,6 +20,9 @@ build_s = time.perf_counter() - t0
 cfg = rt.default_config()
 cfg.Resolution[0], cfg.Resolution[1] = W, H
 ctx = rt.RtContext(0)
+if os.environ.get("RELOAD_COST_PLAIN"):   # as reloads were first built: every release a hipFree, every scene check a full walk
+    ctx.set_tuning("device_pool_mb", 0)
+    ctx.set_tuning("reuse_validation", 0)
 drv = rt.Driver(ctx, cfg, scene)
 for _ in range(4):
     drv.render_frame()
@@ -55,4 +58,32 @@ for k in range(3):
     out["reloads"].append({k2: round(v, 3) for k2, v in step.items()})
 print(json.dumps(out))
 drv.close()
+
+# The RIS project reloads on every camera or object move (BVH_RIS_DL Main.cs:117,122-130): while the camera moves, a
+# reload is part of EVERY frame.  Frames rendered that way against frames without a reload.
+if which == "80k":
+    rcfg = rt.ris_default_config()
+    rcfg.Resolution[0], rcfg.Resolution[1] = W, H
+    rcfg.TriCandidatesNum, rcfg.CandidateReservoirTestsNum = 32, 32
+    rdrv = rt.RisDriver(ctx, rcfg, scene)
+    for _ in range(6):
+        rdrv.render_frame()
+    ctx.sync()
+    n = 20
+    t = time.perf_counter()
+    for _ in range(n):
+        rdrv.render_frame()
+    ctx.sync()
+    plain = (time.perf_counter() - t) / n * 1e3
+    t = time.perf_counter()
+    for k in range(n):
+        scene.set_object_transform(1, (-3.0 + 0.01 * k, -2.0, 12.0), (0.0, 25.0, 0.0), (12.0, 12.0, 12.0))
+        scene.rebuild(keep_old_scene_bvh=False)
+        rdrv.reload()
+        rdrv.render_frame()
+    ctx.sync()
+    moving = (time.perf_counter() - t) / n * 1e3
+    print(json.dumps({"project": "ris", "resolution": [W, H], "candidates_per_pixel": 32, "ms_per_frame": round(plain, 3),
+                      "ms_per_frame_with_a_reload_in_every_frame": round(moving, 3)}))
+    rdrv.close()
 ctx.close()
