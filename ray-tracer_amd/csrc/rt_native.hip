@@ -816,6 +816,10 @@ int subtreeDepth(const std::vector<Link>& bvs, uint32_t root, int64_t nLeafTarge
     return maxDepth;
 }
 
+// Workgroups for k_hash_links: every wave ends with two atomic adds to the same two words, so no more waves than the
+// nodes give work to (a thread takes 16 nodes or more; 1024 workgroups at most).
+dim3 hashGrid(size_t n) { const size_t g = (n + 256 * 16 - 1) / (256 * 16); return dim3((unsigned)(g < 1 ? 1 : g > 1024 ? 1024 : g)); }
+
 // Validates the scene buffers the traversal kernels index without bounds checks and (re)builds the derived
 // device arrays: wide BVH nodes, baked triangles, per-object root entries.  Cached on the buffers' versions.
 // `ris` selects the RIS project's buffer set: "Tris" (76-byte triangles with inline vertices), 32-byte materials, no
@@ -890,7 +894,7 @@ int prepareScene(rt_shader sh, int kernel, KParams& P, bool ris = false) {
             if (!ris)
                 hipLaunchKernelGGL(k_check_tri_indices, dim3((unsigned)((bTris->count + 255) / 256)), dim3(256), 0, S(ctx),
                                    (const rt_triangle*)bTris->dev, bTris->count, bVerts->count, flagDev);
-            if (tryPrefix) hipLaunchKernelGGL(k_hash_links, dim3(1024), dim3(256), 0, S(ctx), (const int2*)scratch.p, (int64_t)knownPrefix, digestDev);
+            if (tryPrefix) hipLaunchKernelGGL(k_hash_links, hashGrid(knownPrefix), dim3(256), 0, S(ctx), (const int2*)scratch.p, (int64_t)knownPrefix, digestDev);
             if (e == hipSuccess) e = hipGetLastError();
             if (e == hipSuccess && tryPrefix) e = hipMemcpyAsync(digest, digestDev, 16, hipMemcpyDeviceToHost, S(ctx));
             if (e == hipSuccess) e = hipMemcpyAsync(&flag, flagDev, 4, hipMemcpyDeviceToHost, S(ctx));
@@ -972,7 +976,7 @@ int prepareScene(rt_shader sh, int kernel, KParams& P, bool ris = false) {
             known.digest[0] = known.digest[1] = 0;
             if (known.nPrefix > 0 && !known.meshes.empty()) {
                 hipError_t e = hipMemsetAsync(digestDev, 0, 16, S(ctx));
-                hipLaunchKernelGGL(k_hash_links, dim3(1024), dim3(256), 0, S(ctx), (const int2*)scratch.p, (int64_t)known.nPrefix, digestDev);
+                hipLaunchKernelGGL(k_hash_links, hashGrid(known.nPrefix), dim3(256), 0, S(ctx), (const int2*)scratch.p, (int64_t)known.nPrefix, digestDev);
                 if (e == hipSuccess) e = hipGetLastError();
                 if (e == hipSuccess) e = hipMemcpyAsync(known.digest, digestDev, 16, hipMemcpyDeviceToHost, S(ctx));
                 if (e == hipSuccess) e = hipStreamSynchronize(S(ctx));

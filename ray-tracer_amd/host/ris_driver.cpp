@@ -40,6 +40,8 @@ struct rth_ris_main_s {
     // MeshHelper.LoadMesh (:33-73) + Utils.TrisFromTri2s + the parent-index pass (:441-450), from the built scene.
     void BuildRisArrays() {
         Tris.resize((size_t)scene.nTriangles);
+        // (on the host's threads: the RIS project reloads with every camera move, so this runs once per frame then)
+#pragma omp parallel for schedule(static) if (scene.nTriangles > 16384)
         for (int64_t i = 0; i < scene.nTriangles; i++) {
             const rt_triangle& t = scene.Triangles[i];
             const rt_vertex &a = scene.Vertices[t.vertex0Index], &b = scene.Vertices[t.vertex1Index], &c = scene.Vertices[t.vertex2Index];
