@@ -13,6 +13,8 @@ pub() {   # <tag> [make_pmc_profile arguments]
 }
 pub restir_80k_1920x1080
 pub restir_unique_3840x2160 --scene unique --width 3840 --height 2160
+pub restir_80k_3840x2160 --width 3840 --height 2160
+pub restir_instanced_3840x2160 --scene instanced --width 3840 --height 2160
 pub ris_80k_1920x1080 --project ris
 cp gpurun_out/bench_final.json profiles/${R}_bench.json
 cp gpurun_out/bench_under_rocprof.json profiles/${R}_bench_under_rocprof.json
