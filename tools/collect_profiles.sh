@@ -2,10 +2,10 @@
 # Collects everything under profiles/ for the current build on the GPU box: kernel trace, PMC passes, bench lines.
 # Each rocprofv3 pass is a run of its own (counters are never combined with traces).  Afterwards, here:
 #   bash tools/publish_profiles.sh
-# usage: bash tools/collect_profiles.sh [default|unique4k|4k|instanced4k|ris|benches ...]   (no argument: all of them)
+# usage: bash tools/collect_profiles.sh [default|unique4k|4k|instanced4k|256|ris|benches ...]   (no argument: all of them)
 export TMPDIR=/tmp
 set -e
-what=${@:-default unique4k 4k instanced4k ris benches}
+what=${@:-default unique4k 4k instanced4k 256 ris benches}
 passes() {   # <tag> [bench.py arguments]
     tag=$1; shift
     bash tools/pmc_pass.sh $tag fetch "FETCH_SIZE" "$@"
@@ -23,6 +23,8 @@ default)
 unique4k)
     passes restir_unique_3840x2160 --scene unique --width 3840 --height 2160
     timeout -s KILL 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/ktrace_unique4k -- python3 bench.py --no-cpu-baseline --scene unique --width 3840 --height 2160 --steps 16 --warmup 4 > gpurun_out/bench_unique4k_under_rocprof.json 2> gpurun_out/ktrace_unique4k.err ;;
+256)
+    passes restir_80k_256x256_tri_reservoir_tests32 --width 256 --height 256 --tri-reservoir-tests 32 ;;
 4k)
     passes restir_80k_3840x2160 --width 3840 --height 2160 ;;
 instanced4k)

@@ -47,6 +47,7 @@ ap.add_argument("--height", type=int, default=1080)
 ap.add_argument("--scene", default="80k")
 ap.add_argument("--project", default="restir")
 ap.add_argument("--small-scene", action="store_true")
+ap.add_argument("--tri-reservoir-tests", type=int, default=None)
 args, _ = ap.parse_known_args()
 d = args.dir
 fetch, write = read(f"{d}/fetch_summary.txt"), read(f"{d}/write_summary.txt")
@@ -74,7 +75,8 @@ for name in fetch:
         k["l2_requests_per_launch"] = tcc[name]["TCC_REQ_sum"]
     kernels[name] = k
 json.dump({"workload": "bench.py with the arguments of `config` under rocprofv3 --pmc, one pass per counter group (tools/collect_profiles.sh)",
-           "config": {"width": args.width, "height": args.height, "world": 1, "small_scene": args.small_scene, "scene": args.scene, "project": args.project},
+           "config": dict({"width": args.width, "height": args.height, "world": 1, "small_scene": args.small_scene, "scene": args.scene, "project": args.project},
+                          **({"tri_reservoir_tests": args.tri_reservoir_tests} if args.tri_reservoir_tests is not None else {})),
            "source_hash": bench.source_hash(),
            "correction": "hbm bytes = FETCH_SIZE*1024*2 + WRITE_SIZE*1024 (gfx950: FETCH_SIZE counts 128-byte requests at 64 bytes)",
            "kernels": kernels}, sys.stdout, indent=1)

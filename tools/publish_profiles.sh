@@ -15,6 +15,7 @@ pub restir_80k_1920x1080
 pub restir_unique_3840x2160 --scene unique --width 3840 --height 2160
 pub restir_80k_3840x2160 --width 3840 --height 2160
 pub restir_instanced_3840x2160 --scene instanced --width 3840 --height 2160
+pub restir_80k_256x256_tri_reservoir_tests32 --width 256 --height 256 --tri-reservoir-tests 32
 pub ris_80k_1920x1080 --project ris
 cp gpurun_out/bench_final.json profiles/${R}_bench.json
 cp gpurun_out/bench_under_rocprof.json profiles/${R}_bench_under_rocprof.json
