@@ -9,6 +9,9 @@ HBM before the timed region.  N > 1 splits the same image into N row bands, one 
 torch.distributed.run), with reservoir halos exchanged between neighbours once per frame and the displayed
 image gathered on rank 0 (strong scaling).  Rank 0 prints ONE JSON line.
 
+The headline run (no workload flags) also times the same frame at 3840x2160 on the same ranks, after everything
+else, and reports it as `also_3840x2160`: the multi-GPU target is stated for that resolution.  `--no-4k` leaves it out.
+
 value = rays cast by all ranks in the K timed frames / wall time of those frames, in Mrays/s (primary + shadow +
 light rays, counted by the kernels themselves in the timed region).  The roofline figure is for the kernel that
 dominates the frame: its launches are bracketed by HIP events inside the timed region; the per-kernel table of the
@@ -171,6 +174,8 @@ def main():
     ap.add_argument("--exchange", choices=("rccl", "torch"), default="rccl",
                     help="N > 1: halo exchange from the C++ frame loop with RCCL calls (default), or from Python with "
                          "torch.distributed's NCCL backend")
+    ap.add_argument("--no-4k", action="store_true",
+                    help="headline run only: leave out the extra measurement of the same frame at 3840x2160 (`also_3840x2160`)")
     ap.add_argument("--tuning", action="append", default=[], metavar="NAME=VALUE",
                     help="rt_set_tuning(NAME, VALUE) before the first frame (experiments; repeatable)")
     args = ap.parse_args()
@@ -328,6 +333,63 @@ def main():
         per_rank = [None] * world
         dist.all_gather_object(per_rank, mine)
 
+    # The headline run also measures the SAME frame at 3840x2160 on the same ranks - the configuration the multi-GPU
+    # target is stated for (BASELINE.json configs[3]) - and reports it beside the 1080p figures (`also_3840x2160`):
+    # a second runner of the same kind, its own warm-up, the same barrier / max-over-ranks timing.  It never changes
+    # `value`; whatever goes wrong in it is reported in its place.
+    also_4k = None
+    headline = (not ris and args.scene == "80k" and (W, H) == (1920, 1080) and not args.small_scene
+                and args.tri_reservoir_tests is None and not args.emissive_fans and not args.tuning)
+    if headline and not args.no_4k and (world == 1 or type(runner).__name__ == "RcclRunner"):
+        runner4 = None
+        try:
+            cfg4 = rt.default_config()
+            cfg4.Resolution[0], cfg4.Resolution[1] = 3840, 2160
+            if world == 1:
+                runner4 = SingleRunner(rt, scene, cfg4)
+            else:
+                runner4 = mg.RcclRunner(rt, scene, cfg4, rank, world, local_rank)
+            ctx4 = runner4.ctx
+            ctx4.enable_stats(1)
+            steps4 = max(1, min(args.steps, 24))
+
+            def render4(n):
+                if hasattr(runner4, "render_frames"):
+                    runner4.render_frames(n)
+                else:
+                    for _ in range(n):
+                        runner4.render_frame()
+
+            render4(max(2, min(args.warmup, 8)))
+            runner4.sync()
+            ctx4.profile_reset()
+            ctx4.profile_enable(True, only="trace_rays")
+            runner4.barrier()
+            t4 = time.perf_counter()
+            render4(steps4)
+            runner4.sync()
+            runner4.barrier()
+            dt4 = time.perf_counter() - t4
+            ctx4.profile_enable(False)
+            rays4 = sum(k["rays"] for k in ctx4.profile().values())
+            dt4_max, rays4_total = runner4.reduce(dt4, rays4)
+            also_4k = {"workload": "the same scene and settings at 3840x2160 (BASELINE.json configs[3])", "n_gpus": world,
+                       "steps": steps4, "ms_per_step": dt4_max / steps4 * 1e3, "value": rays4_total / 1e6 / dt4_max, "unit": "Mrays/s",
+                       "rays_per_frame": rays4_total / steps4}
+            if world > 1:
+                also_4k["rows_of_rank"] = [int(b) for b in runner4.bounds]
+        except Exception as e:  # noqa: BLE001 - reported, never fatal for the headline line
+            also_4k = {"error": f"{type(e).__name__}: {e}"}
+        finally:
+            if runner4 is not None:
+                try:
+                    if world > 1:
+                        runner4.close(keep_group=True)
+                    else:
+                        runner4.close()
+                except Exception:  # noqa: BLE001
+                    pass
+
     if rank == 0:
         proj = "BVH_RIS_DL" if ris else "BVH_ReSTIR_DL"
         band_px = runner.band_pixels()
@@ -420,6 +482,8 @@ def main():
                              f"the other kernels in {n_breakdown} untimed frames after it" +
                              ("; isolated_avg_ms: 8 untimed frames before it with one frame in flight and no overlapped primary rays" if isolated else ""),
         }
+        if also_4k:
+            out["also_3840x2160"] = also_4k
         if per_rank:
             out["per_rank_frame_ms"] = per_rank
             out["per_rank_note"] = ("8 further frames, each waited for; 'frame' is dispatch-stream time, 'halo_exchange' and "

@@ -430,11 +430,12 @@ class RcclRunner:
             self.host.rth_mg_enable_timing(self.h, 0)
         return {k: float(v) for k, v in zip(self.TIME_NAMES, out)}
 
-    def close(self):
+    def close(self, keep_group=False):
+        """keep_group: the torch.distributed side channel stays up (another runner of this process still uses it)."""
         if self.h:
             self.host.rth_mg_destroy(self.h)
             self.h = None
         self.drv.close()
         self.ctx.close()
-        if self.world > 1 and dist.is_initialized():
+        if self.world > 1 and dist.is_initialized() and not keep_group:
             dist.destroy_process_group()

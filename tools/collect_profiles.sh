@@ -18,7 +18,7 @@ for w in $what; do
 case $w in
 default)
     timeout -k 10 200 python3 bench.py > gpurun_out/bench_final.json 2> gpurun_out/bench_final.err
-    timeout -s KILL 240 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/ktrace -- python3 bench.py --no-cpu-baseline > gpurun_out/bench_under_rocprof.json 2> gpurun_out/ktrace.err
+    timeout -s KILL 240 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/ktrace -- python3 bench.py --no-cpu-baseline --no-4k > gpurun_out/bench_under_rocprof.json 2> gpurun_out/ktrace.err
     passes restir_80k_1920x1080 ;;
 unique4k)
     passes restir_unique_3840x2160 --scene unique --width 3840 --height 2160
